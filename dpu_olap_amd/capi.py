@@ -1,0 +1,303 @@
+"""ctypes binding of include/olap_gpu.h (libolap_gpu.so).
+
+This is the only way Python reaches the hot path: there is NO CPU fallback.  If
+the HIP library is missing or no GPU is visible, loading / creating a context
+raises -- tests that need the GPU are marked `gpu`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Iterable, Sequence
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libolap_gpu.so")
+
+OLAP_OK = 0
+ERR_INVALID, ERR_DEVICE, ERR_NOMEM, ERR_NO_MATCH, ERR_OVERFLOW, ERR_CAPACITY = -1, -2, -3, -4, -5, -6
+U32, I32, U64, I64 = 0, 1, 2, 3
+MEM_HOST, MEM_DEVICE = 0, 1
+
+DTYPE_BYTES = {U32: 4, I32: 4, U64: 8, I64: 8}
+DTYPE_FROM_NUMPY = {"uint32": U32, "int32": I32, "uint64": U64, "int64": I64}
+NUMPY_FROM_DTYPE = {U32: "uint32", I32: "int32", U64: "uint64", I64: "int64"}
+
+# every symbol include/olap_gpu.h declares (checked by tests/test_capi_symbols.py)
+EXPORTS = [
+    "olap_abi_version", "olap_create", "olap_destroy", "olap_last_error", "olap_device_info",
+    "olap_set_stream", "olap_get_stream", "olap_synchronize", "olap_reserve_workspace",
+    "olap_workspace_bytes", "olap_malloc", "olap_free", "olap_memcpy_h2d", "olap_memcpy_d2h",
+    "olap_memset", "olap_set_profiling", "olap_reset_timers", "olap_get_timers", "olap_filter_lt",
+    "olap_sum", "olap_take", "olap_partition_u32", "olap_join_u32", "olap_join_configure",
+    "olap_gen_uniform_u32", "olap_gen_uniform_u64", "olap_gen_index_u32", "olap_gen_fk_u32",
+    "olap_gen_uniform_u32_at", "olap_checksum", "olap_checksum_rows3_u32",
+]
+
+
+class OlapError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"olap error {code}: {message}")
+        self.code = code
+        self.message = message
+
+
+class JoinStats(C.Structure):
+    _fields_ = [
+        ("passes", C.c_uint32),
+        ("radix_bits", C.c_uint32 * 4),
+        ("nr_partitions", C.c_uint32),
+        ("table_slots", C.c_uint32),
+        ("left_rows", C.c_uint64),
+        ("right_rows", C.c_uint64),
+        ("max_build_rows", C.c_uint64),
+        ("duplicate_keys", C.c_uint64),
+        ("missing_keys", C.c_uint64),
+    ]
+
+    def as_dict(self) -> dict:
+        return {
+            "passes": self.passes,
+            "radix_bits": list(self.radix_bits)[: self.passes],
+            "nr_partitions": self.nr_partitions,
+            "table_slots": self.table_slots,
+            "left_rows": self.left_rows,
+            "right_rows": self.right_rows,
+            "max_build_rows": self.max_build_rows,
+            "duplicate_keys": self.duplicate_keys,
+            "missing_keys": self.missing_keys,
+        }
+
+
+_lib = None
+
+
+def load_library(path: str | None = None) -> C.CDLL:
+    """dlopen libolap_gpu.so and declare the prototypes.  Raises if it is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise ImportError(
+            f"{p} not found: build the HIP extension first (python -m dpu_olap_amd.build). "
+            "There is no CPU fallback for the operator hot path."
+        )
+    L = C.CDLL(p)
+    vp, u64, u32, i = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
+    pvp, pu64 = C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)
+    sig = {
+        "olap_abi_version": (i, []),
+        "olap_create": (i, [i, pvp]),
+        "olap_destroy": (None, [vp]),
+        "olap_last_error": (C.c_char_p, [vp]),
+        "olap_device_info": (i, [vp, C.c_char_p, C.c_size_t, C.POINTER(i), pu64, pu64]),
+        "olap_set_stream": (i, [vp, vp]),
+        "olap_get_stream": (vp, [vp]),
+        "olap_synchronize": (i, [vp]),
+        "olap_reserve_workspace": (i, [vp, u64]),
+        "olap_workspace_bytes": (u64, [vp]),
+        "olap_malloc": (i, [vp, u64, pvp]),
+        "olap_free": (i, [vp, vp]),
+        "olap_memcpy_h2d": (i, [vp, vp, vp, u64]),
+        "olap_memcpy_d2h": (i, [vp, vp, vp, u64]),
+        "olap_memset": (i, [vp, vp, i, u64]),
+        "olap_set_profiling": (i, [vp, i]),
+        "olap_reset_timers": (i, [vp]),
+        "olap_get_timers": (i, [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_double), pu64, i, C.POINTER(i)]),
+        "olap_filter_lt": (i, [vp, i, pvp, pu64, u64, i, vp, pvp, i, pu64, pu64]),
+        "olap_sum": (i, [vp, i, pvp, pu64, u64, i, pu64]),
+        "olap_take": (i, [vp, i, pvp, pu64, pvp, pu64, u64, i, pvp, i]),
+        "olap_partition_u32": (i, [vp, pvp, pvp, pu64, u64, i, u32, vp, vp, u64, i, pu64]),
+        "olap_join_u32": (i, [vp, pvp, pvp, pu64, u64, pvp, pvp, pu64, u64, i, vp, vp, vp, u64, i, pu64,
+                              C.POINTER(JoinStats)]),
+        "olap_join_configure": (i, [vp, i, i]),
+        "olap_gen_uniform_u32": (i, [vp, vp, u64, u64, u32, u64]),
+        "olap_gen_uniform_u64": (i, [vp, vp, u64, u64, u32, u64]),
+        "olap_gen_index_u32": (i, [vp, vp, u64, u32]),
+        "olap_gen_fk_u32": (i, [vp, vp, u64, u64, u32, u64, u64, u64]),
+        "olap_gen_uniform_u32_at": (i, [vp, vp, vp, u64, u64, u32]),
+        "olap_checksum": (i, [vp, vp, u64, i, pu64]),
+        "olap_checksum_rows3_u32": (i, [vp, vp, vp, vp, u64, pu64]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = L
+    return L
+
+
+def _ptr_table(ptrs: Sequence[int]):
+    arr = (C.c_void_p * max(len(ptrs), 1))()
+    for k, p in enumerate(ptrs):
+        arr[k] = p
+    return arr
+
+
+def _u64_table(vals: Iterable[int]):
+    vals = list(vals)
+    arr = (C.c_uint64 * max(len(vals), 1))()
+    for k, v in enumerate(vals):
+        arr[k] = v
+    return arr
+
+
+class Context:
+    """One olap_ctx == one GPU.  Plays the role of dpu::DpuSet in the reference
+    (host/dpuext/dpuext.hpp:709-715)."""
+
+    def __init__(self, device_id: int = 0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.olap_create(device_id, C.byref(h))
+        if rc != OLAP_OK or not h:
+            raise OlapError(rc, f"olap_create(device {device_id}) failed: no usable HIP device")
+        self.h = h
+        self.device_id = device_id
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.olap_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- helpers
+    def _check(self, rc: int):
+        if rc != OLAP_OK:
+            raise OlapError(rc, (self.lib.olap_last_error(self.h) or b"").decode())
+
+    def device_info(self) -> dict:
+        name = C.create_string_buffer(256)
+        cus, tot, fr = C.c_int(), C.c_uint64(), C.c_uint64()
+        self._check(self.lib.olap_device_info(self.h, name, 256, C.byref(cus), C.byref(tot), C.byref(fr)))
+        return {"name": name.value.decode(), "compute_units": cus.value, "total_mem": tot.value, "free_mem": fr.value}
+
+    def set_stream(self, hip_stream: int | None):
+        self._check(self.lib.olap_set_stream(self.h, hip_stream))
+
+    def get_stream(self) -> int:
+        return self.lib.olap_get_stream(self.h) or 0
+
+    def synchronize(self):
+        self._check(self.lib.olap_synchronize(self.h))
+
+    def reserve_workspace(self, nbytes: int):
+        self._check(self.lib.olap_reserve_workspace(self.h, nbytes))
+
+    def workspace_bytes(self) -> int:
+        return self.lib.olap_workspace_bytes(self.h)
+
+    def malloc(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        self._check(self.lib.olap_malloc(self.h, nbytes, C.byref(p)))
+        return p.value or 0
+
+    def free(self, dptr: int):
+        self._check(self.lib.olap_free(self.h, dptr))
+
+    def h2d(self, dst: int, src_host_ptr: int, nbytes: int):
+        self._check(self.lib.olap_memcpy_h2d(self.h, dst, src_host_ptr, nbytes))
+
+    def d2h(self, dst_host_ptr: int, src: int, nbytes: int):
+        self._check(self.lib.olap_memcpy_d2h(self.h, dst_host_ptr, src, nbytes))
+
+    def memset(self, dst: int, value: int, nbytes: int):
+        self._check(self.lib.olap_memset(self.h, dst, value, nbytes))
+
+    def set_profiling(self, on: bool):
+        self._check(self.lib.olap_set_profiling(self.h, 1 if on else 0))
+
+    def reset_timers(self):
+        self._check(self.lib.olap_reset_timers(self.h))
+
+    def timers(self) -> dict:
+        cap = 32
+        names = (C.c_char_p * cap)()
+        ms = (C.c_double * cap)()
+        launches = (C.c_uint64 * cap)()
+        n = C.c_int()
+        self._check(self.lib.olap_get_timers(self.h, names, ms, launches, cap, C.byref(n)))
+        return {names[k].decode(): {"ms": ms[k], "launches": launches[k]} for k in range(min(n.value, cap))}
+
+    # -- operators (raw pointer level)
+    def filter_lt(self, dtype: int, ptrs, rows, in_mem: int, threshold, out_ptrs, out_mem: int):
+        nb = len(ptrs)
+        ct = {U32: C.c_uint32, I32: C.c_int32, U64: C.c_uint64, I64: C.c_int64}[dtype]
+        thr = ct(threshold)
+        out_rows = (C.c_uint64 * max(nb, 1))()
+        total = C.c_uint64()
+        self._check(self.lib.olap_filter_lt(self.h, dtype, _ptr_table(ptrs), _u64_table(rows), nb, in_mem,
+                                            C.cast(C.byref(thr), C.c_void_p), _ptr_table(out_ptrs), out_mem,
+                                            out_rows, C.byref(total)))
+        return [out_rows[k] for k in range(nb)], total.value
+
+    def sum(self, dtype: int, ptrs, rows, in_mem: int) -> int:
+        out = C.c_uint64()
+        self._check(self.lib.olap_sum(self.h, dtype, _ptr_table(ptrs), _u64_table(rows), len(ptrs), in_mem, C.byref(out)))
+        v = out.value
+        if dtype in (I32, I64) and v >= 1 << 63:
+            v -= 1 << 64
+        return v
+
+    def take(self, dtype: int, data_ptrs, data_rows, idx_ptrs, idx_rows, in_mem: int, out_ptrs, out_mem: int):
+        self._check(self.lib.olap_take(self.h, dtype, _ptr_table(data_ptrs), _u64_table(data_rows), _ptr_table(idx_ptrs),
+                                       _u64_table(idx_rows), len(data_ptrs), in_mem, _ptr_table(out_ptrs), out_mem))
+
+    def partition_u32(self, key_ptrs, payload_ptrs, rows, in_mem: int, nr_partitions: int, out_keys: int,
+                      out_payload: int, out_capacity: int, out_mem: int):
+        offs = (C.c_uint64 * (nr_partitions + 1))()
+        pay = _ptr_table(payload_ptrs) if payload_ptrs is not None else None
+        self._check(self.lib.olap_partition_u32(self.h, _ptr_table(key_ptrs), pay, _u64_table(rows), len(key_ptrs), in_mem,
+                                                nr_partitions, out_keys, out_payload, out_capacity, out_mem, offs))
+        return [offs[k] for k in range(nr_partitions + 1)]
+
+    def join_configure(self, radix_bits_total: int = -1, max_bits_per_pass: int = 0):
+        self._check(self.lib.olap_join_configure(self.h, radix_bits_total, max_bits_per_pass))
+
+    def join_u32(self, lfk, ly, lrows, rpk, rx, rrows, in_mem: int, out_fk: int, out_y: int, out_x: int,
+                 out_capacity: int, out_mem: int):
+        n = C.c_uint64()
+        st = JoinStats()
+        self._check(self.lib.olap_join_u32(self.h, _ptr_table(lfk), _ptr_table(ly), _u64_table(lrows), len(lfk),
+                                           _ptr_table(rpk), _ptr_table(rx), _u64_table(rrows), len(rpk), in_mem,
+                                           out_fk, out_y, out_x, out_capacity, out_mem, C.byref(n), C.byref(st)))
+        return n.value, st.as_dict()
+
+    # -- generator / digests
+    def gen_uniform_u32(self, out: int, n: int, seed: int, stream_id: int, first_row: int = 0):
+        self._check(self.lib.olap_gen_uniform_u32(self.h, out, n, seed, stream_id, first_row))
+
+    def gen_uniform_u64(self, out: int, n: int, seed: int, stream_id: int, first_row: int = 0):
+        self._check(self.lib.olap_gen_uniform_u64(self.h, out, n, seed, stream_id, first_row))
+
+    def gen_index_u32(self, out: int, n: int, first_value: int = 0):
+        self._check(self.lib.olap_gen_index_u32(self.h, out, n, first_value))
+
+    def gen_fk_u32(self, out: int, n: int, seed: int, stream_id: int, first_row: int, left_batch_rows: int,
+                   right_batch_rows: int):
+        self._check(self.lib.olap_gen_fk_u32(self.h, out, n, seed, stream_id, first_row, left_batch_rows, right_batch_rows))
+
+    def gen_uniform_u32_at(self, out: int, rows_dev: int, n: int, seed: int, stream_id: int):
+        self._check(self.lib.olap_gen_uniform_u32_at(self.h, out, rows_dev, n, seed, stream_id))
+
+    def checksum(self, col: int, n: int, elem_bytes: int):
+        out = (C.c_uint64 * 3)()
+        self._check(self.lib.olap_checksum(self.h, col, n, elem_bytes, out))
+        return out[0], out[1], out[2]
+
+    def checksum_rows3_u32(self, a: int, b: int, c: int, n: int):
+        out = (C.c_uint64 * 2)()
+        self._check(self.lib.olap_checksum_rows3_u32(self.h, a, b, c, n, out))
+        return out[0], out[1]

@@ -1,0 +1,227 @@
+// common.h -- context, error handling, batched-column views and device helpers
+// shared by the HIP translation units of libolap_gpu.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "olap_gpu.h"
+
+namespace olap {
+
+constexpr int kWave = 64;  // CDNA wavefront
+
+// ---------------------------------------------------------------- phases
+enum Phase : int {
+  PH_COPY_TO = 0,
+  PH_COPY_FROM,
+  PH_SUM,
+  PH_FILTER_COUNT,
+  PH_FILTER_COMPACT,
+  PH_TAKE,
+  PH_PART_HIST,
+  PH_PART_SCAN,
+  PH_PART_SCATTER,
+  PH_JOIN_PROBE,
+  PH_GEN,
+  PH_COUNT
+};
+
+extern const char* const kPhaseNames[PH_COUNT];
+
+struct PhaseTimer {
+  double ms = 0.0;
+  uint64_t launches = 0;
+};
+
+}  // namespace olap
+
+// The opaque handle of include/olap_gpu.h.
+struct olap_ctx {
+  int device = 0;
+  int compute_units = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  mutable std::string err;
+
+  // scratch arena (device) -- one allocation, bump-carved per operator call
+  char* ws = nullptr;
+  uint64_t ws_bytes = 0;
+  uint64_t ws_used = 0;
+  // pinned host scratch for pointer tables / small results
+  char* pinned = nullptr;
+  uint64_t pinned_bytes = 0;
+  uint64_t pinned_used = 0;
+
+  // profiling
+  bool profiling = false;
+  olap::PhaseTimer timers[olap::PH_COUNT];
+  struct Pending {
+    int phase;
+    hipEvent_t a, b;
+  };
+  std::vector<Pending> pending;
+  std::vector<hipEvent_t> event_pool;
+
+  // join tuning
+  int radix_bits_total = -1;
+  int max_bits_per_pass = 0;
+
+  int fail(int code, const char* fmt, ...) const {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    err = buf;
+    return code;
+  }
+};
+
+#define OLAP_HIP(ctx, call)                                                              \
+  do {                                                                                   \
+    hipError_t e__ = (call);                                                             \
+    if (e__ != hipSuccess)                                                               \
+      return (ctx)->fail(OLAP_ERR_DEVICE, "%s failed: %s (%s:%d)", #call,                \
+                         hipGetErrorString(e__), __FILE__, __LINE__);                    \
+  } while (0)
+
+#define OLAP_TRY(expr)            \
+  do {                            \
+    int rc__ = (expr);            \
+    if (rc__ != OLAP_OK) return rc__; \
+  } while (0)
+
+namespace olap {
+
+// ---- context services (ctx.hip)
+int ws_begin(olap_ctx* ctx, uint64_t bytes);                 // ensure capacity, reset bump pointer
+void* ws_alloc(olap_ctx* ctx, uint64_t bytes);               // 256-B aligned carve (nullptr if exhausted)
+int pinned_begin(olap_ctx* ctx, uint64_t bytes);
+void* pinned_alloc(olap_ctx* ctx, uint64_t bytes);
+void phase_begin(olap_ctx* ctx, int phase);                  // record start event if profiling
+void phase_end(olap_ctx* ctx, int phase);                    // record stop event if profiling
+int resolve_timers(olap_ctx* ctx);                           // after a sync: fold pending events
+
+struct PhaseScope {
+  olap_ctx* ctx;
+  int phase;
+  PhaseScope(olap_ctx* c, int p) : ctx(c), phase(p) { phase_begin(ctx, phase); }
+  ~PhaseScope() { phase_end(ctx, phase); }
+};
+
+inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
+inline uint32_t dtype_bytes(int dtype) { return (dtype == OLAP_U32 || dtype == OLAP_I32) ? 4u : 8u; }
+inline bool dtype_ok(int dtype) { return dtype >= OLAP_U32 && dtype <= OLAP_I64; }
+
+// A set of batches (one data buffer per batch) cut into fixed-size units of
+// `unit_rows` rows that never straddle a batch.  unit u of the view belongs to
+// batch b = locate(u) and covers rows [lu*unit_rows, ...) of that batch.
+struct ColView {
+  const uint64_t* unit_start;  // [nb+1] prefix sum of units per batch (device)
+  const uint64_t* row_start;   // [nb+1] prefix sum of rows per batch (device)
+  uint64_t total_units;
+  uint64_t total_rows;
+  uint32_t nb;
+  uint32_t unit_rows;
+  uint32_t units_per_batch;  // > 0 when every batch has the same row count
+  uint32_t uniform_rows;     // that row count (valid when units_per_batch > 0)
+};
+
+// Host-side staging of a batched column set: builds the device tables (and, for
+// OLAP_MEM_HOST inputs, copies the buffers into the arena).
+struct ColumnSet {
+  ColView view{};
+  std::vector<const void* const*> dev_ptr_tables;  // one device pointer table per column
+};
+
+// Builds view tables in the arena.  `cols` = ncols arrays of nb host-side pointers.
+// For in_mem == HOST the data is copied to the arena and the tables point there.
+int build_column_set(olap_ctx* ctx, const void* const* const* cols, int ncols,
+                     const uint32_t* elem_bytes, const uint64_t* rows, uint64_t nb, int in_mem,
+                     uint32_t unit_rows, ColumnSet* out);
+uint64_t column_set_bytes(const uint64_t* rows, uint64_t nb, int ncols, const uint32_t* elem_bytes,
+                          int in_mem);
+
+}  // namespace olap
+
+// ---------------------------------------------------------------- device side
+#if defined(__HIPCC__)
+namespace olap {
+
+// Wang hash -- bit-exact with dpu/shared/kernels/partition.c:20-28 and
+// dpu/shared/hashtable/hashtable.c:29-37 of the reference (checked against the
+// known-answer values in tests/golden/reference_kats.json).
+__host__ __device__ __forceinline__ uint32_t wang_hash(uint32_t key) {
+  key += ~(key << 15);
+  key ^= (key >> 10);
+  key += (key << 3);
+  key ^= (key >> 6);
+  key += ~(key << 11);
+  key ^= (key >> 16);
+  return key;
+}
+
+// 64-bit finaliser (splitmix64) used by the generator and the digests.
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+// Counter-based generator: value of stream `s` at global row `r`.
+__host__ __device__ __forceinline__ uint64_t gen64(uint64_t seed, uint32_t s, uint64_t r) {
+  return mix64(mix64(seed ^ (0xD1B54A32D192ED03ull * (uint64_t)(s + 1))) + r);
+}
+__host__ __device__ __forceinline__ uint32_t gen32(uint64_t seed, uint32_t s, uint64_t r) {
+  return (uint32_t)(gen64(seed, s, r) >> 32);
+}
+
+struct Loc {
+  uint32_t batch;
+  uint64_t local_unit;
+};
+
+__device__ __forceinline__ Loc locate(const ColView& v, uint64_t unit) {
+  Loc l;
+  if (v.units_per_batch) {
+    l.batch = (uint32_t)(unit / v.units_per_batch);
+    l.local_unit = unit - (uint64_t)l.batch * v.units_per_batch;
+  } else {
+    uint32_t lo = 0, hi = v.nb;  // find last b with unit_start[b] <= unit
+    while (hi - lo > 1) {
+      uint32_t mid = (lo + hi) >> 1;
+      if (v.unit_start[mid] <= unit) lo = mid; else hi = mid;
+    }
+    l.batch = lo;
+    l.local_unit = unit - v.unit_start[lo];
+  }
+  return l;
+}
+
+__device__ __forceinline__ uint64_t batch_rows(const ColView& v, uint32_t b) {
+  return v.units_per_batch ? (uint64_t)v.uniform_rows : v.row_start[b + 1] - v.row_start[b];
+}
+
+__device__ __forceinline__ uint64_t batch_row0(const ColView& v, uint32_t b) {
+  return v.units_per_batch ? (uint64_t)b * v.uniform_rows : v.row_start[b];
+}
+
+__device__ __forceinline__ unsigned lane_id() { return threadIdx.x & (kWave - 1); }
+
+__device__ __forceinline__ uint64_t wave_reduce_add(uint64_t x) {
+#pragma unroll
+  for (int o = kWave / 2; o > 0; o >>= 1) x += __shfl_down(x, o, kWave);
+  return x;
+}
+
+}  // namespace olap
+#endif

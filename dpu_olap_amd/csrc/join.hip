@@ -1,0 +1,756 @@
+// join.hip -- radix partition and radix-partitioned PK-FK hash join for gfx950.
+//
+// Reference behaviour (upmem/dpu_olap):
+//   partition  dpu/shared/kernels/partition.c:20-28 (wang hash), :45-46 (bucket =
+//              top bits), :67-92 histogram, :94-137 prefix sum, :233-294 scatter
+//   shuffle    host/partition/partitioner.cc:280-375 (through host DRAM)
+//   build      dpu/shared/kernels/hash_build.c:9-35 + hashtable.c:89-165
+//   probe      dpu/shared/kernels/hash_probe.c:9-46 + hashtable.c:167-192
+//   compose    host/join/join_dpu.cc:168-400
+//
+// MI355X design: tuples (key, payload) are carried through 1..4 MSD radix passes
+// over wang_hash(key) until a partition's build side fits an LDS hash table
+// (8192 slots, 64 KiB, two workgroups per CU).  Each pass is
+//   hist    (per-workgroup LDS histogram -> matrix [workgroup][bucket])
+//   scan    (bucket-major exclusive scan -> cursors, next segment table)
+//   scatter (tile of 8192 tuples: LDS ranks -> LDS staging grouped by bucket ->
+//            coalesced runs written at the workgroup's cursors)
+// so the layout is exact (no capacity slack, no global atomics) and the shuffle
+// of the reference never leaves HBM.  The payload travels with the key, which
+// removes the row-id round trip of the reference (kernel_take after partition).
+// The hash table uses the LOW bits of the same hash, like the reference
+// (hashtable.c:99-101), linear probing, LDS atomicCAS insert.
+// Bound: HBM bandwidth (integer work, no MFMA).
+#include "common.h"
+
+namespace olap {
+
+constexpr int kPBlock = 512;                  // 8 waves per partition workgroup
+constexpr int kPTile = 8192;                  // tuples per tile
+constexpr int kTPT = kPTile / kPBlock;        // 16 tuples per thread
+constexpr int kMaxFBits = 10;                 // <= 1024 buckets per pass
+constexpr int kMaxF = 1 << kMaxFBits;
+constexpr int kMaxPasses = 4;
+constexpr uint32_t kScatterLds = kPTile * 8 + kMaxF * 8 + (kMaxF + 4) * 4 + 64;
+
+constexpr int kJBlock = 512;
+constexpr int kSlots = 8192;                  // LDS hash table slots per partition
+constexpr uint32_t kTableCap = kSlots / 4 * 3;  // max build rows (load <= 0.75, hashtable.h:55)
+constexpr uint32_t kTargetBuildRows = kSlots / 2;
+constexpr uint32_t kEmpty = 0xFFFFFFFFu;
+
+enum { SRC_COLS = 0, SRC_TUPLES = 1 };
+
+// Input of a pass: either the batched key/payload columns (pass 0) or the tuple
+// array of the previous pass cut into segments.
+struct PassSrc {
+  // SRC_COLS
+  ColView v;
+  const void* const* key_ptrs;
+  const void* const* pay_ptrs;  // may be null: payload = global row index
+  uint64_t tiles_per_block;
+  // SRC_TUPLES
+  const uint2* tuples;
+  const uint64_t* seg_off;  // [n_seg + 1]
+  uint32_t n_seg;
+  uint32_t blocks_per_seg;
+};
+
+struct TileRange {
+  uint64_t t0, t1;    // tile ids
+  uint64_t lo, hi;    // SRC_TUPLES: tuple range of the segment
+  uint64_t a;         // SRC_TUPLES: 16-B aligned base (lo & ~1)
+  uint32_t seg;
+};
+
+template <int SRC>
+__device__ __forceinline__ TileRange block_tiles(const PassSrc& s) {
+  TileRange r;
+  if (SRC == SRC_COLS) {
+    r.seg = 0;
+    r.t0 = (uint64_t)blockIdx.x * s.tiles_per_block;
+    r.t1 = min(r.t0 + s.tiles_per_block, s.v.total_units);
+    if (r.t0 > r.t1) r.t0 = r.t1;
+    r.lo = r.hi = r.a = 0;
+  } else {
+    r.seg = blockIdx.x / s.blocks_per_seg;
+    const uint32_t j = blockIdx.x - r.seg * s.blocks_per_seg;
+    r.lo = s.seg_off[r.seg];
+    r.hi = s.seg_off[r.seg + 1];
+    r.a = r.lo & ~1ull;
+    const uint64_t tiles = (r.hi - r.a + kPTile - 1) / kPTile;
+    const uint64_t q = (tiles + s.blocks_per_seg - 1) / s.blocks_per_seg;
+    r.t0 = min((uint64_t)j * q, tiles);
+    r.t1 = min(r.t0 + q, tiles);
+  }
+  return r;
+}
+
+// Loads one tile: 16 tuples per thread, valid bits in the returned mask.
+template <int SRC, bool WANT_PAYLOAD>
+__device__ __forceinline__ uint32_t load_tile(const PassSrc& s, const TileRange& r, uint64_t tile,
+                                              uint32_t (&key)[kTPT], uint32_t (&pay)[kTPT]) {
+  uint32_t mask = 0;
+  if (SRC == SRC_COLS) {
+    const Loc l = locate(s.v, tile);
+    const uint64_t rows = batch_rows(s.v, l.batch);
+    const uint64_t r0 = l.local_unit * kPTile;
+    const uint32_t n = (uint32_t)min((uint64_t)kPTile, rows - r0);
+    const uint32_t* kp = (const uint32_t*)s.key_ptrs[l.batch] + r0;
+    const uint32_t* pp = s.pay_ptrs ? (const uint32_t*)s.pay_ptrs[l.batch] + r0 : nullptr;
+    const uint32_t rowid0 = (uint32_t)(batch_row0(s.v, l.batch) + r0);
+    const bool fast = n == kPTile && ((((uintptr_t)kp) | ((uintptr_t)pp)) & 15) == 0;
+    if (fast) {
+      uint4 kv[kTPT / 4], pv[kTPT / 4];
+#pragma unroll
+      for (int j = 0; j < kTPT / 4; ++j) kv[j] = ((const uint4*)kp)[j * kPBlock + threadIdx.x];
+      if (WANT_PAYLOAD && pp) {
+#pragma unroll
+        for (int j = 0; j < kTPT / 4; ++j) pv[j] = ((const uint4*)pp)[j * kPBlock + threadIdx.x];
+      }
+#pragma unroll
+      for (int j = 0; j < kTPT / 4; ++j) {
+        key[4 * j + 0] = kv[j].x;
+        key[4 * j + 1] = kv[j].y;
+        key[4 * j + 2] = kv[j].z;
+        key[4 * j + 3] = kv[j].w;
+        if (WANT_PAYLOAD) {
+          if (pp) {
+            pay[4 * j + 0] = pv[j].x;
+            pay[4 * j + 1] = pv[j].y;
+            pay[4 * j + 2] = pv[j].z;
+            pay[4 * j + 3] = pv[j].w;
+          } else {
+            const uint32_t i0 = rowid0 + (j * kPBlock + threadIdx.x) * 4;
+            pay[4 * j + 0] = i0;
+            pay[4 * j + 1] = i0 + 1;
+            pay[4 * j + 2] = i0 + 2;
+            pay[4 * j + 3] = i0 + 3;
+          }
+        }
+      }
+      mask = 0xFFFFu;
+    } else {
+#pragma unroll
+      for (int j = 0; j < kTPT / 4; ++j) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const uint32_t idx = (j * kPBlock + threadIdx.x) * 4 + k;
+          const bool ok = idx < n;
+          key[4 * j + k] = ok ? kp[idx] : 0u;
+          if (WANT_PAYLOAD) pay[4 * j + k] = ok ? (pp ? pp[idx] : rowid0 + idx) : 0u;
+          mask |= (ok ? 1u : 0u) << (4 * j + k);
+        }
+      }
+    }
+  } else {
+    const uint64_t base = r.a + tile * (uint64_t)kPTile;
+#pragma unroll
+    for (int j = 0; j < kTPT / 2; ++j) {
+      const uint64_t i0 = base + (uint64_t)(j * kPBlock + threadIdx.x) * 2;
+      uint4 t = make_uint4(0, 0, 0, 0);
+      if (i0 < r.hi) t = *(const uint4*)(s.tuples + i0);  // array is padded by 2 tuples
+      key[2 * j] = t.x;
+      pay[2 * j] = t.y;
+      key[2 * j + 1] = t.z;
+      pay[2 * j + 1] = t.w;
+      mask |= ((i0 >= r.lo && i0 < r.hi) ? 1u : 0u) << (2 * j);
+      mask |= ((i0 + 1 >= r.lo && i0 + 1 < r.hi) ? 1u : 0u) << (2 * j + 1);
+    }
+  }
+  return mask;
+}
+
+// ------------------------------------------------------------------ hist
+template <int SRC>
+__global__ __launch_bounds__(kPBlock) void k_part_hist(PassSrc s, uint32_t shift, uint32_t fbits,
+                                                       uint32_t* hist) {
+  __shared__ uint32_t cl[kMaxF];
+  const uint32_t F = 1u << fbits;
+  for (uint32_t b = threadIdx.x; b < F; b += kPBlock) cl[b] = 0;
+  __syncthreads();
+  const TileRange r = block_tiles<SRC>(s);
+  for (uint64_t tile = r.t0; tile < r.t1; ++tile) {
+    uint32_t key[kTPT], pay[kTPT];
+    const uint32_t mask = load_tile<SRC, false>(s, r, tile, key, pay);
+#pragma unroll
+    for (int i = 0; i < kTPT; ++i) {
+      if (mask & (1u << i)) atomicAdd(&cl[(wang_hash(key[i]) >> shift) & (F - 1)], 1u);
+    }
+  }
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < F; b += kPBlock) hist[(uint64_t)blockIdx.x * F + b] = cl[b];
+}
+
+// ------------------------------------------------------------------ scan
+// One workgroup per input segment.  hist[(seg*Bseg + blk)*F + b] (counts) is
+// replaced by the exclusive prefix over blk; seg_off_out[seg*F + b] receives the
+// absolute start of output bucket (seg, b) -- the segment table of the next pass.
+__global__ __launch_bounds__(1024) void k_part_scan(uint32_t* hist, const uint64_t* seg_off_in,
+                                                    uint64_t total_in, uint32_t n_seg, uint32_t Bseg,
+                                                    uint32_t fbits, uint64_t* seg_off_out) {
+  __shared__ uint64_t s_wave[16];
+  const uint32_t F = 1u << fbits;
+  const uint32_t seg = blockIdx.x;
+  const uint32_t b = threadIdx.x;
+  uint64_t tot = 0;
+  if (b < F) {
+    uint32_t run = 0;
+    uint32_t* col = hist + (uint64_t)seg * Bseg * F + b;
+    uint32_t blk = 0;
+    for (; blk + 4 <= Bseg; blk += 4) {  // 4 independent loads in flight
+      const uint32_t c0 = col[(uint64_t)(blk + 0) * F], c1 = col[(uint64_t)(blk + 1) * F];
+      const uint32_t c2 = col[(uint64_t)(blk + 2) * F], c3 = col[(uint64_t)(blk + 3) * F];
+      col[(uint64_t)(blk + 0) * F] = run;
+      col[(uint64_t)(blk + 1) * F] = run + c0;
+      col[(uint64_t)(blk + 2) * F] = run + c0 + c1;
+      col[(uint64_t)(blk + 3) * F] = run + c0 + c1 + c2;
+      tot += (uint64_t)c0 + c1 + c2 + c3;
+      run += c0 + c1 + c2 + c3;
+    }
+    for (; blk < Bseg; ++blk) {
+      const uint32_t c = col[(uint64_t)blk * F];
+      col[(uint64_t)blk * F] = run;
+      run += c;
+      tot += c;
+    }
+  }
+  uint64_t incl = tot;
+#pragma unroll
+  for (int o = 1; o < kWave; o <<= 1) {
+    const uint64_t y = __shfl_up(incl, o, kWave);
+    if ((int)lane_id() >= o) incl += y;
+  }
+  if (lane_id() == kWave - 1) s_wave[threadIdx.x / kWave] = incl;
+  __syncthreads();
+  uint64_t off = seg_off_in ? seg_off_in[seg] : 0;
+  for (unsigned w = 0; w < threadIdx.x / kWave; ++w) off += s_wave[w];
+  if (b < F) seg_off_out[(uint64_t)seg * F + b] = off + incl - tot;
+  if (seg == n_seg - 1 && threadIdx.x == 0)
+    seg_off_out[(uint64_t)n_seg * F] = seg_off_in ? seg_off_in[n_seg] : total_in;
+}
+
+// --------------------------------------------------------------- scatter
+template <int SRC>
+__global__ __launch_bounds__(kPBlock, 4) void k_part_scatter(PassSrc s, uint32_t shift, uint32_t fbits,
+                                                             const uint32_t* hist,
+                                                             const uint64_t* seg_off_out, uint2* out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint2* stage = (uint2*)smem;                                          // kPTile tuples
+  uint64_t* gcur = (uint64_t*)(smem + kPTile * 8);                       // F cursors
+  uint32_t* cl = (uint32_t*)(smem + kPTile * 8 + kMaxF * 8);             // F + 1 counts / local starts
+  uint32_t* wtot = cl + (kMaxF + 4);                                     // 8 wave totals
+  const uint32_t F = 1u << fbits;
+  const uint32_t BPT = (F + kPBlock - 1) / kPBlock;  // bins per thread: 1 or 2
+  const TileRange r = block_tiles<SRC>(s);
+  for (uint32_t b = threadIdx.x; b < F; b += kPBlock) {
+    gcur[b] = seg_off_out[(uint64_t)r.seg * F + b] + hist[(uint64_t)blockIdx.x * F + b];
+    cl[b] = 0;
+  }
+  __syncthreads();
+  const unsigned lane = lane_id();
+  const unsigned wave = threadIdx.x / kWave;
+  for (uint64_t tile = r.t0; tile < r.t1; ++tile) {
+    uint32_t key[kTPT], pay[kTPT], br[kTPT];
+    const uint32_t mask = load_tile<SRC, true>(s, r, tile, key, pay);
+    // (2) bucket + rank inside the bucket
+#pragma unroll
+    for (int i = 0; i < kTPT; ++i) {
+      br[i] = 0;
+      if (mask & (1u << i)) {
+        const uint32_t b = (wang_hash(key[i]) >> shift) & (F - 1);
+        br[i] = (b << 16) | atomicAdd(&cl[b], 1u);
+      }
+    }
+    __syncthreads();
+    // (3) exclusive scan of the bucket counts, in place; counts stay in registers
+    uint32_t cnt[2] = {0, 0};
+    uint32_t local = 0;
+    const uint32_t bin0 = threadIdx.x * BPT;
+    for (uint32_t q = 0; q < BPT; ++q) {
+      if (bin0 + q < F) {
+        cnt[q] = cl[bin0 + q];
+        local += cnt[q];
+      }
+    }
+    uint32_t incl = local;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+      const uint32_t y = __shfl_up(incl, o, kWave);
+      if ((int)lane >= o) incl += y;
+    }
+    if (lane == kWave - 1) wtot[wave] = incl;
+    __syncthreads();
+    uint32_t pre = incl - local;
+    uint32_t n_tile = 0;
+#pragma unroll
+    for (int w = 0; w < kPBlock / kWave; ++w) {
+      if ((unsigned)w < wave) pre += wtot[w];
+      n_tile += wtot[w];
+    }
+    for (uint32_t q = 0; q < BPT; ++q) {
+      if (bin0 + q < F) {
+        cl[bin0 + q] = pre;
+        pre += cnt[q];
+      }
+    }
+    __syncthreads();
+    // (4) tuples into the staging area, grouped by bucket
+#pragma unroll
+    for (int i = 0; i < kTPT; ++i) {
+      if (mask & (1u << i)) stage[cl[br[i] >> 16] + (br[i] & 0xFFFFu)] = make_uint2(key[i], pay[i]);
+    }
+    __syncthreads();
+    // (5) coalesced copy-out: consecutive lanes -> consecutive addresses inside a run
+#pragma unroll 4
+    for (uint32_t i = threadIdx.x; i < n_tile; i += kPBlock) {
+      const uint2 t = stage[i];
+      const uint32_t b = (wang_hash(t.x) >> shift) & (F - 1);
+      out[gcur[b] + (i - cl[b])] = t;
+    }
+    __syncthreads();
+    // (6) advance the cursors, clear the counts
+    for (uint32_t q = 0; q < BPT; ++q) {
+      if (bin0 + q < F) {
+        gcur[bin0 + q] += cnt[q];
+        cl[bin0 + q] = 0;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------ build + probe
+// counters: [0] missing keys, [1] duplicate build keys, [2] overflowing
+// partitions, [3] max build rows
+__global__ __launch_bounds__(kJBlock, 4) void k_join_probe(const uint2* R, const uint64_t* r_off,
+                                                           const uint2* L, const uint64_t* l_off,
+                                                           uint32_t nparts, uint32_t* out_fk,
+                                                           uint32_t* out_y, uint32_t* out_x,
+                                                           unsigned long long* counters) {
+  __shared__ uint32_t s_keys[kSlots];
+  __shared__ uint32_t s_vals[kSlots];
+  __shared__ uint32_t s_sp[2];  // the one key equal to the empty marker: {present, value}
+  uint32_t my_miss = 0, my_dup = 0;
+  uint64_t my_max = 0;
+  for (uint32_t p = blockIdx.x; p < nparts; p += gridDim.x) {
+    const uint64_t rlo = r_off[p], rhi = r_off[p + 1];
+    const uint64_t llo = l_off[p], lhi = l_off[p + 1];
+    const uint64_t n_r = rhi - rlo, n_l = lhi - llo;
+    if (n_r > my_max) my_max = n_r;
+    if (n_l == 0) continue;
+    if (n_r > kTableCap) {
+      if (threadIdx.x == 0) atomicAdd(&counters[2], 1ull);
+      continue;
+    }
+    for (uint32_t i = threadIdx.x; i < kSlots; i += kJBlock) s_keys[i] = kEmpty;
+    if (threadIdx.x == 0) s_sp[0] = 0;
+    __syncthreads();
+    // build: table[pk] = payload (hash_build.c:24-31; value = right payload instead of row index)
+    for (uint32_t i = threadIdx.x; i < (uint32_t)n_r; i += kJBlock) {
+      const uint2 t = R[rlo + i];
+      if (t.x == kEmpty) {
+        s_sp[1] = t.y;
+        if (atomicExch(&s_sp[0], 1u)) ++my_dup;
+      } else {
+        uint32_t slot = wang_hash(t.x) & (kSlots - 1);
+        for (uint32_t step = 0; step < kSlots; ++step) {
+          const uint32_t old = atomicCAS(&s_keys[slot], kEmpty, t.x);
+          if (old == kEmpty || old == t.x) {  // free cell, or equal key overwrites (hashtable.c:133)
+            s_vals[slot] = t.y;
+            if (old == t.x) ++my_dup;
+            break;
+          }
+          slot = (slot + 1) & (kSlots - 1);
+        }
+      }
+    }
+    __syncthreads();
+    // probe (hash_probe.c:26-36) fused with the take of the right payload
+    for (uint32_t i = threadIdx.x; i < (uint32_t)n_l; i += kJBlock) {
+      const uint2 t = L[llo + i];
+      uint32_t x = 0;
+      bool hit = false;
+      if (t.x == kEmpty) {
+        hit = s_sp[0] != 0;
+        x = s_sp[1];
+      } else {
+        uint32_t slot = wang_hash(t.x) & (kSlots - 1);
+        for (uint32_t step = 0; step < kSlots; ++step) {
+          const uint32_t k = s_keys[slot];
+          if (k == t.x) {
+            x = s_vals[slot];
+            hit = true;
+            break;
+          }
+          if (k == kEmpty) break;
+          slot = (slot + 1) & (kSlots - 1);
+        }
+      }
+      if (!hit) ++my_miss;
+      out_fk[llo + i] = t.x;
+      out_y[llo + i] = t.y;
+      out_x[llo + i] = x;
+    }
+    __syncthreads();
+  }
+  const uint64_t wm = wave_reduce_add((uint64_t)my_miss);
+  const uint64_t wd = wave_reduce_add((uint64_t)my_dup);
+  if (lane_id() == 0) {
+    if (wm) atomicAdd(&counters[0], (unsigned long long)wm);
+    if (wd) atomicAdd(&counters[1], (unsigned long long)wd);
+  }
+  if (threadIdx.x == 0) atomicMax(&counters[3], (unsigned long long)my_max);
+}
+
+__global__ __launch_bounds__(256) void k_unzip(const uint2* t, uint64_t n, uint32_t* keys, uint32_t* pay) {
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+    const uint2 v = t[i];
+    keys[i] = v.x;
+    pay[i] = v.y;
+  }
+}
+
+// ------------------------------------------------------------------ host
+struct PassPlan {
+  int passes = 0;
+  uint32_t bits[kMaxPasses] = {0, 0, 0, 0};
+  uint32_t total_bits = 0;
+};
+
+static int ceil_log2_u64(uint64_t x) {
+  int l = 0;
+  while ((1ull << l) < x) ++l;
+  return l;
+}
+
+static int make_plan(olap_ctx* ctx, uint32_t total_bits, PassPlan* plan) {
+  int maxb = ctx->max_bits_per_pass > 0 ? ctx->max_bits_per_pass : kMaxFBits;
+  if (maxb > kMaxFBits) maxb = kMaxFBits;
+  if (total_bits < 1) total_bits = 1;
+  const int passes = ((int)total_bits + maxb - 1) / maxb;
+  if (passes > kMaxPasses)
+    return ctx->fail(OLAP_ERR_INVALID, "%u radix bits need %d passes (max %d)", total_bits, passes, kMaxPasses);
+  plan->passes = passes;
+  plan->total_bits = total_bits;
+  const uint32_t base = total_bits / passes, extra = total_bits % passes;
+  for (int i = 0; i < passes; ++i) plan->bits[i] = base + ((uint32_t)i < extra ? 1u : 0u);
+  return OLAP_OK;
+}
+
+struct SideBuffers {
+  uint2* final_tuples = nullptr;    // rows + 2
+  uint64_t* final_off = nullptr;    // [P + 1]
+};
+
+static uint64_t seg_blocks(const olap_ctx* ctx, uint64_t n_seg) {
+  uint64_t want = (uint64_t)ctx->compute_units * 4;
+  uint64_t b = (want + n_seg - 1) / n_seg;
+  if (b < 1) b = 1;
+  if (b > 256) b = 256;
+  return b;
+}
+
+// workspace bytes one side needs besides its final tuple buffer and the shared temps
+static uint64_t side_scratch_bytes(const olap_ctx* ctx, uint64_t rows, const PassPlan& plan) {
+  uint64_t bytes = 0;
+  uint64_t n_seg = 1;
+  const uint64_t tiles = (rows + kPTile - 1) / kPTile + 1;
+  for (int i = 0; i < plan.passes; ++i) {
+    const uint64_t F = 1ull << plan.bits[i];
+    uint64_t blocks;
+    if (i == 0) {
+      blocks = (uint64_t)ctx->compute_units * 2;
+      if (blocks > tiles) blocks = tiles;
+    } else {
+      blocks = n_seg * seg_blocks(ctx, n_seg);
+    }
+    bytes += align_up(blocks * F * 4, 256);          // hist matrix
+    bytes += align_up((n_seg * F + 1) * 8, 256);     // segment table
+    n_seg *= F;
+  }
+  return bytes + 4096;
+}
+
+// Runs all passes of one side.  `cs` views the key/payload columns with unit_rows = kPTile.
+static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, const PassPlan& plan,
+                          uint2* tmp0, uint2* tmp1, uint2* final_tuples, uint64_t** final_off) {
+  const uint64_t rows = cs.view.total_rows;
+  PassSrc src{};
+  src.v = cs.view;
+  src.key_ptrs = cs.dev_ptr_tables[0];
+  src.pay_ptrs = has_payload ? cs.dev_ptr_tables[1] : nullptr;
+  uint64_t n_seg = 1;
+  const uint64_t* seg_in = nullptr;
+  const uint2* in_tuples = nullptr;
+  uint32_t consumed = 0;
+  OLAP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_scatter<SRC_COLS>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, kScatterLds));
+  OLAP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_scatter<SRC_TUPLES>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, kScatterLds));
+  for (int i = 0; i < plan.passes; ++i) {
+    const uint32_t fbits = plan.bits[i];
+    const uint64_t F = 1ull << fbits;
+    consumed += fbits;
+    const uint32_t shift = 32 - consumed;
+    uint2* out = (i == plan.passes - 1) ? final_tuples : ((i & 1) ? tmp1 : tmp0);
+    uint64_t blocks, bseg;
+    if (i == 0) {
+      const uint64_t tiles = cs.view.total_units;
+      uint64_t nb = (uint64_t)ctx->compute_units * 2;
+      if (nb > tiles) nb = tiles;
+      if (nb == 0) nb = 1;
+      src.tiles_per_block = (tiles + nb - 1) / nb;
+      if (src.tiles_per_block == 0) src.tiles_per_block = 1;
+      blocks = (tiles + src.tiles_per_block - 1) / src.tiles_per_block;
+      if (blocks == 0) blocks = 1;
+      bseg = blocks;
+    } else {
+      bseg = seg_blocks(ctx, n_seg);
+      blocks = n_seg * bseg;
+      src.tuples = in_tuples;
+      src.seg_off = seg_in;
+      src.n_seg = (uint32_t)n_seg;
+      src.blocks_per_seg = (uint32_t)bseg;
+    }
+    if (blocks > 0x7FFFFFFFull) return ctx->fail(OLAP_ERR_INVALID, "partition grid too large");
+    uint32_t* hist = (uint32_t*)ws_alloc(ctx, blocks * F * 4);
+    uint64_t* seg_out = (uint64_t*)ws_alloc(ctx, (n_seg * F + 1) * 8);
+    if (!hist || !seg_out) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (partition pass %d)", i);
+    {
+      PhaseScope ps(ctx, PH_PART_HIST);
+      if (i == 0)
+        hipLaunchKernelGGL((k_part_hist<SRC_COLS>), dim3((unsigned)blocks), dim3(kPBlock), 0, ctx->stream, src, shift, fbits, hist);
+      else
+        hipLaunchKernelGGL((k_part_hist<SRC_TUPLES>), dim3((unsigned)blocks), dim3(kPBlock), 0, ctx->stream, src, shift, fbits, hist);
+      OLAP_HIP(ctx, hipGetLastError());
+    }
+    {
+      PhaseScope ps(ctx, PH_PART_SCAN);
+      hipLaunchKernelGGL(k_part_scan, dim3((unsigned)n_seg), dim3(1024), 0, ctx->stream, hist, seg_in, rows,
+                         (uint32_t)n_seg, (uint32_t)bseg, fbits, seg_out);
+      OLAP_HIP(ctx, hipGetLastError());
+    }
+    {
+      PhaseScope ps(ctx, PH_PART_SCATTER);
+      if (i == 0)
+        hipLaunchKernelGGL((k_part_scatter<SRC_COLS>), dim3((unsigned)blocks), dim3(kPBlock), kScatterLds, ctx->stream,
+                           src, shift, fbits, (const uint32_t*)hist, (const uint64_t*)seg_out, out);
+      else
+        hipLaunchKernelGGL((k_part_scatter<SRC_TUPLES>), dim3((unsigned)blocks), dim3(kPBlock), kScatterLds, ctx->stream,
+                           src, shift, fbits, (const uint32_t*)hist, (const uint64_t*)seg_out, out);
+      OLAP_HIP(ctx, hipGetLastError());
+    }
+    in_tuples = out;
+    seg_in = seg_out;
+    n_seg *= F;
+  }
+  *final_off = const_cast<uint64_t*>(seg_in);
+  return OLAP_OK;
+}
+
+static int check_side(olap_ctx* ctx, const void* keys, const uint64_t* rows, uint64_t nb, uint64_t* total) {
+  if (nb && (!keys || !rows)) return ctx->fail(OLAP_ERR_INVALID, "null batch table");
+  uint64_t t = 0;
+  for (uint64_t b = 0; b < nb; ++b) t += rows[b];
+  if (t > (1ull << 32)) return ctx->fail(OLAP_ERR_INVALID, "more than 2^32 rows on one side");
+  *total = t;
+  return OLAP_OK;
+}
+
+static int join_once(olap_ctx* ctx, const uint32_t* const* lfk, const uint32_t* const* ly, const uint64_t* lrows,
+                     uint64_t lnb, const uint32_t* const* rpk, const uint32_t* const* rx, const uint64_t* rrows,
+                     uint64_t rnb, int in_mem, uint32_t* out_fk, uint32_t* out_y, uint32_t* out_x, int out_mem,
+                     uint64_t NL, uint64_t NR, uint32_t total_bits, olap_join_stats* st, unsigned long long counters[4]) {
+  PassPlan plan;
+  OLAP_TRY(make_plan(ctx, total_bits, &plan));
+  const uint32_t P = 1u << plan.total_bits;
+  const uint32_t eb[2] = {4, 4};
+  const void* const* lcols[2] = {(const void* const*)lfk, (const void* const*)ly};
+  const void* const* rcols[2] = {(const void* const*)rpk, (const void* const*)rx};
+  const uint64_t maxN = NL > NR ? NL : NR;
+  uint64_t need = column_set_bytes(lrows, lnb, 2, eb, in_mem) + column_set_bytes(rrows, rnb, 2, eb, in_mem) +
+                  side_scratch_bytes(ctx, NL, plan) + side_scratch_bytes(ctx, NR, plan) +
+                  align_up((NL + 2) * 8, 256) + align_up((NR + 2) * 8, 256) + 8192;
+  if (plan.passes >= 2) need += align_up((maxN + 2) * 8, 256);
+  if (plan.passes >= 3) need += align_up((maxN + 2) * 8, 256);
+  if (out_mem == OLAP_MEM_HOST) need += 3 * align_up(NL * 4 + 4, 256);
+  OLAP_TRY(pinned_begin(ctx, (lnb + rnb + 2) * 8 * 8 + 8192));
+  OLAP_TRY(ws_begin(ctx, need));
+  ColumnSet lcs, rcs;
+  OLAP_TRY(build_column_set(ctx, lcols, 2, eb, lrows, lnb, in_mem, kPTile, &lcs));
+  OLAP_TRY(build_column_set(ctx, rcols, 2, eb, rrows, rnb, in_mem, kPTile, &rcs));
+  uint2* tmp0 = plan.passes >= 2 ? (uint2*)ws_alloc(ctx, (maxN + 2) * 8) : nullptr;
+  uint2* tmp1 = plan.passes >= 3 ? (uint2*)ws_alloc(ctx, (maxN + 2) * 8) : nullptr;
+  uint2* Lt = (uint2*)ws_alloc(ctx, (NL + 2) * 8);
+  uint2* Rt = (uint2*)ws_alloc(ctx, (NR + 2) * 8);
+  unsigned long long* d_cnt = (unsigned long long*)ws_alloc(ctx, 32);
+  uint32_t *d_fk = out_fk, *d_y = out_y, *d_x = out_x;
+  if (out_mem == OLAP_MEM_HOST) {
+    d_fk = (uint32_t*)ws_alloc(ctx, NL * 4 + 4);
+    d_y = (uint32_t*)ws_alloc(ctx, NL * 4 + 4);
+    d_x = (uint32_t*)ws_alloc(ctx, NL * 4 + 4);
+  }
+  if ((plan.passes >= 2 && !tmp0) || (plan.passes >= 3 && !tmp1) || !Lt || !Rt || !d_cnt || !d_fk || !d_y || !d_x)
+    return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (join buffers)");
+  OLAP_HIP(ctx, hipMemsetAsync(d_cnt, 0, 32, ctx->stream));
+  uint64_t *l_off = nullptr, *r_off = nullptr;
+  OLAP_TRY(partition_side(ctx, lcs, true, plan, tmp0, tmp1, Lt, &l_off));
+  OLAP_TRY(partition_side(ctx, rcs, true, plan, tmp0, tmp1, Rt, &r_off));
+  {
+    PhaseScope ps(ctx, PH_JOIN_PROBE);
+    uint64_t grid = (uint64_t)ctx->compute_units * 8;
+    if (grid > P) grid = P;
+    hipLaunchKernelGGL(k_join_probe, dim3((unsigned)grid), dim3(kJBlock), 0, ctx->stream, (const uint2*)Rt,
+                       (const uint64_t*)r_off, (const uint2*)Lt, (const uint64_t*)l_off, P, d_fk, d_y, d_x, d_cnt);
+    OLAP_HIP(ctx, hipGetLastError());
+  }
+  OLAP_HIP(ctx, hipMemcpyAsync(counters, d_cnt, 32, hipMemcpyDeviceToHost, ctx->stream));
+  OLAP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (out_mem == OLAP_MEM_HOST && counters[2] == 0 && counters[0] == 0 && NL) {
+    PhaseScope ps(ctx, PH_COPY_FROM);
+    OLAP_HIP(ctx, hipMemcpyAsync(out_fk, d_fk, NL * 4, hipMemcpyDeviceToHost, ctx->stream));
+    OLAP_HIP(ctx, hipMemcpyAsync(out_y, d_y, NL * 4, hipMemcpyDeviceToHost, ctx->stream));
+    OLAP_HIP(ctx, hipMemcpyAsync(out_x, d_x, NL * 4, hipMemcpyDeviceToHost, ctx->stream));
+    OLAP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  if (st) {
+    st->passes = plan.passes;
+    for (int i = 0; i < 4; ++i) st->radix_bits[i] = plan.bits[i];
+    st->nr_partitions = P;
+    st->table_slots = kSlots;
+    st->left_rows = NL;
+    st->right_rows = NR;
+    st->max_build_rows = counters[3];
+    st->duplicate_keys = counters[1];
+    st->missing_keys = counters[0];
+  }
+  return resolve_timers(ctx);
+}
+
+}  // namespace olap
+
+using namespace olap;
+
+extern "C" {
+
+int olap_join_configure(olap_ctx* ctx, int radix_bits_total, int max_bits_per_pass) {
+  if (!ctx) return OLAP_ERR_INVALID;
+  if (radix_bits_total > 30 || max_bits_per_pass > kMaxFBits || max_bits_per_pass < 0)
+    return ctx->fail(OLAP_ERR_INVALID, "bad join configuration");
+  ctx->radix_bits_total = radix_bits_total;
+  ctx->max_bits_per_pass = max_bits_per_pass;
+  return OLAP_OK;
+}
+
+int olap_join_u32(olap_ctx* ctx, const uint32_t* const* left_fk_ptrs, const uint32_t* const* left_y_ptrs,
+                  const uint64_t* left_rows, uint64_t n_left_batches, const uint32_t* const* right_pk_ptrs,
+                  const uint32_t* const* right_x_ptrs, const uint64_t* right_rows, uint64_t n_right_batches,
+                  int in_mem, uint32_t* out_fk, uint32_t* out_y, uint32_t* out_x, uint64_t out_capacity,
+                  int out_mem, uint64_t* out_rows, olap_join_stats* stats) {
+  if (!ctx) return OLAP_ERR_INVALID;
+  if (hipSetDevice(ctx->device) != hipSuccess) return ctx->fail(OLAP_ERR_DEVICE, "hipSetDevice failed");
+  if ((in_mem != OLAP_MEM_HOST && in_mem != OLAP_MEM_DEVICE) || (out_mem != OLAP_MEM_HOST && out_mem != OLAP_MEM_DEVICE))
+    return ctx->fail(OLAP_ERR_INVALID, "bad memory space");
+  if (!out_rows) return ctx->fail(OLAP_ERR_INVALID, "out_rows is null");
+  uint64_t NL = 0, NR = 0;
+  OLAP_TRY(check_side(ctx, left_fk_ptrs, left_rows, n_left_batches, &NL));
+  OLAP_TRY(check_side(ctx, right_pk_ptrs, right_rows, n_right_batches, &NR));
+  if ((n_left_batches && !left_y_ptrs) || (n_right_batches && !right_x_ptrs))
+    return ctx->fail(OLAP_ERR_INVALID, "null payload table");
+  if (stats) std::memset(stats, 0, sizeof *stats);
+  *out_rows = 0;
+  if (NL == 0) return OLAP_OK;
+  if (NL > out_capacity) return ctx->fail(OLAP_ERR_CAPACITY, "output capacity %llu < %llu left rows",
+                                          (unsigned long long)out_capacity, (unsigned long long)NL);
+  if (!out_fk || !out_y || !out_x) return ctx->fail(OLAP_ERR_INVALID, "null output column");
+  if (NR == 0) {
+    if (stats) { stats->left_rows = NL; stats->missing_keys = NL; }
+    return ctx->fail(OLAP_ERR_NO_MATCH, "right table is empty: %llu foreign keys without a match", (unsigned long long)NL);
+  }
+  uint32_t bits;
+  if (ctx->radix_bits_total >= 0) {
+    bits = ctx->radix_bits_total < 1 ? 1u : (uint32_t)ctx->radix_bits_total;
+  } else {
+    bits = (uint32_t)ceil_log2_u64((NR + kTargetBuildRows - 1) / kTargetBuildRows);
+    if (bits < 1) bits = 1;
+  }
+  unsigned long long counters[4] = {0, 0, 0, 0};
+  for (int attempt = 0; attempt < 3; ++attempt) {
+    OLAP_TRY(join_once(ctx, left_fk_ptrs, left_y_ptrs, left_rows, n_left_batches, right_pk_ptrs, right_x_ptrs,
+                       right_rows, n_right_batches, in_mem, out_fk, out_y, out_x, out_mem, NL, NR, bits, stats,
+                       counters));
+    if (counters[2] == 0) break;
+    bits += 2;  // a build partition overflowed the LDS table: split finer and retry
+    if (bits > 28) break;
+  }
+  if (counters[2])
+    return ctx->fail(OLAP_ERR_OVERFLOW, "%llu partition(s) exceed the LDS hash table (%u rows); largest build partition %llu rows",
+                     counters[2], kTableCap, counters[3]);
+  if (counters[0])
+    return ctx->fail(OLAP_ERR_NO_MATCH, "%llu foreign key(s) without a matching primary key", counters[0]);
+  *out_rows = NL;
+  return OLAP_OK;
+}
+
+int olap_partition_u32(olap_ctx* ctx, const uint32_t* const* key_ptrs, const uint32_t* const* payload_ptrs,
+                       const uint64_t* rows, uint64_t n_batches, int in_mem, uint32_t nr_partitions,
+                       uint32_t* out_keys, uint32_t* out_payload, uint64_t out_capacity, int out_mem,
+                       uint64_t* out_offsets) {
+  if (!ctx) return OLAP_ERR_INVALID;
+  if (hipSetDevice(ctx->device) != hipSuccess) return ctx->fail(OLAP_ERR_DEVICE, "hipSetDevice failed");
+  if ((in_mem != OLAP_MEM_HOST && in_mem != OLAP_MEM_DEVICE) || (out_mem != OLAP_MEM_HOST && out_mem != OLAP_MEM_DEVICE))
+    return ctx->fail(OLAP_ERR_INVALID, "bad memory space");
+  // dpu/join/main.c:87-89: power of two, at least 2
+  if (nr_partitions < 2 || (nr_partitions & (nr_partitions - 1)) || nr_partitions > (1u << 20))
+    return ctx->fail(OLAP_ERR_INVALID, "nr_partitions must be a power of two in [2, 2^20]");
+  if (!out_offsets) return ctx->fail(OLAP_ERR_INVALID, "out_offsets is null");
+  uint64_t N = 0;
+  OLAP_TRY(check_side(ctx, key_ptrs, rows, n_batches, &N));
+  if (N > out_capacity) return ctx->fail(OLAP_ERR_CAPACITY, "output capacity too small");
+  if (N && (!out_keys || !out_payload)) return ctx->fail(OLAP_ERR_INVALID, "null output column");
+  PassPlan plan;
+  const int saved = ctx->max_bits_per_pass;
+  OLAP_TRY(make_plan(ctx, (uint32_t)ceil_log2_u64(nr_partitions), &plan));
+  (void)saved;
+  const uint32_t eb[2] = {4, 4};
+  const int ncols = payload_ptrs ? 2 : 1;
+  const void* const* cols[2] = {(const void* const*)key_ptrs, (const void* const*)payload_ptrs};
+  uint64_t need = column_set_bytes(rows, n_batches, ncols, eb, in_mem) + side_scratch_bytes(ctx, N, plan) +
+                  align_up((N + 2) * 8, 256) * (uint64_t)(plan.passes >= 3 ? 3 : plan.passes) + 8192;
+  if (out_mem == OLAP_MEM_HOST) need += 2 * align_up(N * 4 + 4, 256);
+  OLAP_TRY(pinned_begin(ctx, (n_batches + 2) * 8 * 4 + ((uint64_t)nr_partitions + 1) * 8 + 8192));
+  OLAP_TRY(ws_begin(ctx, need));
+  ColumnSet cs;
+  OLAP_TRY(build_column_set(ctx, cols, ncols, eb, rows, n_batches, in_mem, kPTile, &cs));
+  uint2* tmp0 = plan.passes >= 2 ? (uint2*)ws_alloc(ctx, (N + 2) * 8) : nullptr;
+  uint2* tmp1 = plan.passes >= 3 ? (uint2*)ws_alloc(ctx, (N + 2) * 8) : nullptr;
+  uint2* fin = (uint2*)ws_alloc(ctx, (N + 2) * 8);
+  uint32_t *d_k = out_keys, *d_p = out_payload;
+  if (out_mem == OLAP_MEM_HOST) {
+    d_k = (uint32_t*)ws_alloc(ctx, N * 4 + 4);
+    d_p = (uint32_t*)ws_alloc(ctx, N * 4 + 4);
+  }
+  if ((plan.passes >= 2 && !tmp0) || (plan.passes >= 3 && !tmp1) || !fin || (N && (!d_k || !d_p)))
+    return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (partition buffers)");
+  uint64_t* off = nullptr;
+  OLAP_TRY(partition_side(ctx, cs, payload_ptrs != nullptr, plan, tmp0, tmp1, fin, &off));
+  if (N) {
+    PhaseScope ps(ctx, PH_PART_SCATTER);
+    uint64_t grid = (N + 255) / 256;
+    const uint64_t cap = (uint64_t)ctx->compute_units * 16;
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL(k_unzip, dim3((unsigned)grid), dim3(256), 0, ctx->stream, (const uint2*)fin, N, d_k, d_p);
+    OLAP_HIP(ctx, hipGetLastError());
+  }
+  OLAP_HIP(ctx, hipMemcpyAsync(out_offsets, off, ((uint64_t)nr_partitions + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (out_mem == OLAP_MEM_HOST && N) {
+    PhaseScope ps(ctx, PH_COPY_FROM);
+    OLAP_HIP(ctx, hipMemcpyAsync(out_keys, d_k, N * 4, hipMemcpyDeviceToHost, ctx->stream));
+    OLAP_HIP(ctx, hipMemcpyAsync(out_payload, d_p, N * 4, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  OLAP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return resolve_timers(ctx);
+}
+
+}  // extern "C"

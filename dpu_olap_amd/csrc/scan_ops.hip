@@ -1,0 +1,590 @@
+// scan_ops.hip -- sum, filter (order-preserving stream compaction) and take
+// (gather) over batched Arrow integer columns, hand-written for gfx950.
+//
+// Reference behaviour (upmem/dpu_olap):
+//   sum    dpu/shared/kernels/aggr.c:16-33 + dpu/aggr/main.c:44-50,76-88
+//   filter dpu/shared/kernels/filter.c:25,57-177
+//   take   dpu/shared/kernels/take.c:12-47
+// All three are HBM-bandwidth bound: 16-byte-per-lane coalesced loads, wave64
+// ballot / popcount ranks for the compaction, one u64 atomic per workgroup for
+// the sum.  No MFMA.
+#include "common.h"
+
+namespace olap {
+
+constexpr int kBlock = 256;          // 4 waves
+constexpr int kVecPerThread = 4;     // 16-B vectors per thread per tile
+constexpr int kTileBytes = kBlock * kVecPerThread * 16;  // 16 KiB per tile
+
+template <typename T>
+struct Vec16;
+template <>
+struct Vec16<uint32_t> { using type = uint4; };
+template <>
+struct Vec16<int32_t> { using type = int4; };
+template <>
+struct Vec16<uint64_t> { using type = ulonglong2; };
+template <>
+struct Vec16<int64_t> { using type = longlong2; };
+
+template <typename T>
+__device__ __forceinline__ T vec_get(const typename Vec16<T>::type& v, int k);
+template <>
+__device__ __forceinline__ uint32_t vec_get<uint32_t>(const uint4& v, int k) {
+  return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w;
+}
+template <>
+__device__ __forceinline__ int32_t vec_get<int32_t>(const int4& v, int k) {
+  return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w;
+}
+template <>
+__device__ __forceinline__ uint64_t vec_get<uint64_t>(const ulonglong2& v, int k) {
+  return k == 0 ? v.x : v.y;
+}
+template <>
+__device__ __forceinline__ int64_t vec_get<int64_t>(const longlong2& v, int k) {
+  return k == 0 ? v.x : v.y;
+}
+
+// ------------------------------------------------------------------ sum
+// One tile = 16 KiB of one batch.  Grid-stride over tiles; per-lane 64-bit
+// accumulator; wave shuffle reduce; LDS across the 4 waves; one atomic per block.
+template <typename T, typename ACC>
+__global__ __launch_bounds__(kBlock) void k_sum(ColView v, const void* const* ptrs,
+                                                unsigned long long* out) {
+  constexpr int E = 16 / sizeof(T);
+  constexpr uint32_t TILE = kBlock * kVecPerThread * E;
+  using V = typename Vec16<T>::type;
+  ACC acc = 0;
+  for (uint64_t tile = blockIdx.x; tile < v.total_units; tile += gridDim.x) {
+    Loc l = locate(v, tile);
+    const uint64_t rows = batch_rows(v, l.batch);
+    const uint64_t r0 = l.local_unit * TILE;
+    const uint32_t n = (uint32_t)min((uint64_t)TILE, rows - r0);
+    const T* p = (const T*)ptrs[l.batch] + r0;
+    if (n == TILE && (((uintptr_t)p) & 15) == 0) {
+      const V* pv = (const V*)p;
+      V x[kVecPerThread];
+#pragma unroll
+      for (int j = 0; j < kVecPerThread; ++j) x[j] = pv[j * kBlock + threadIdx.x];
+#pragma unroll
+      for (int j = 0; j < kVecPerThread; ++j)
+#pragma unroll
+        for (int k = 0; k < E; ++k) acc += (ACC)vec_get<T>(x[j], k);
+    } else {
+      for (uint32_t i = threadIdx.x; i < n; i += kBlock) acc += (ACC)p[i];
+    }
+  }
+  __shared__ unsigned long long s_part[kBlock / kWave];
+  unsigned long long w = wave_reduce_add((unsigned long long)acc);
+  if (lane_id() == 0) s_part[threadIdx.x / kWave] = w;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t = 0;
+#pragma unroll
+    for (int i = 0; i < kBlock / kWave; ++i) t += s_part[i];
+    atomicAdd(out, t);
+  }
+}
+
+// --------------------------------------------------------------- filter
+// Work unit = segment: up to seg_rows consecutive rows of one batch, processed
+// by ONE workgroup tile after tile with a running output offset, so a batch
+// that is a single segment (the reference's 64 Ki-row batches) needs no
+// inter-workgroup communication at all.  Batches longer than a segment use a
+// count pass + per-batch scan of the segment counts first.
+//
+// Rank of an element inside a tile (order preserving):
+//   round j (kBlock vectors = kBlock*E consecutive rows), wave w, lane l:
+//   c = number of passing elements among the lane's E elements (0..E);
+//   exclusive lane prefix from three ballots (bit planes of c) + popcount of the
+//   lanes below; wave totals of all rounds go through LDS once per tile.
+template <typename T>
+__device__ __forceinline__ void filter_tile_flags(const T* p, uint32_t n, uint32_t TILE, bool fast,
+                                                  T thr, T (&val)[kVecPerThread][16 / sizeof(T)],
+                                                  uint32_t (&flags)[kVecPerThread]) {
+  constexpr int E = 16 / sizeof(T);
+  using V = typename Vec16<T>::type;
+  if (fast) {
+    const V* pv = (const V*)p;
+    V x[kVecPerThread];
+#pragma unroll
+    for (int j = 0; j < kVecPerThread; ++j) x[j] = pv[j * kBlock + threadIdx.x];
+#pragma unroll
+    for (int j = 0; j < kVecPerThread; ++j) {
+      uint32_t f = 0;
+#pragma unroll
+      for (int k = 0; k < E; ++k) {
+        val[j][k] = vec_get<T>(x[j], k);
+        f |= (val[j][k] < thr ? 1u : 0u) << k;
+      }
+      flags[j] = f;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < kVecPerThread; ++j) {
+      uint32_t f = 0;
+#pragma unroll
+      for (int k = 0; k < E; ++k) {
+        uint32_t idx = (j * kBlock + threadIdx.x) * E + k;
+        T x = idx < n ? p[idx] : thr;  // thr itself never passes `x < thr`
+        val[j][k] = x;
+        f |= ((idx < n && x < thr) ? 1u : 0u) << k;
+      }
+      flags[j] = f;
+    }
+  }
+  (void)TILE;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_filter_count(ColView sv, const void* const* in_ptrs, T thr,
+                                                         uint32_t* seg_count) {
+  constexpr int E = 16 / sizeof(T);
+  constexpr uint32_t TILE = kBlock * kVecPerThread * E;
+  __shared__ uint32_t s_part[kBlock / kWave];
+  for (uint64_t seg = blockIdx.x; seg < sv.total_units; seg += gridDim.x) {
+    Loc l = locate(sv, seg);
+    const uint64_t rows = batch_rows(sv, l.batch);
+    const uint64_t r0 = l.local_unit * sv.unit_rows;
+    const uint32_t n_seg = (uint32_t)min((uint64_t)sv.unit_rows, rows - r0);
+    const T* in = (const T*)in_ptrs[l.batch] + r0;
+    const bool aligned = (((uintptr_t)in) & 15) == 0;
+    uint32_t cnt = 0;
+    for (uint32_t t0 = 0; t0 < n_seg; t0 += TILE) {
+      const uint32_t n = min(TILE, n_seg - t0);
+      T val[kVecPerThread][E];
+      uint32_t flags[kVecPerThread];
+      filter_tile_flags<T>(in + t0, n, TILE, aligned && n == TILE, thr, val, flags);
+#pragma unroll
+      for (int j = 0; j < kVecPerThread; ++j) cnt += __popc(flags[j]);
+    }
+    uint32_t w = (uint32_t)wave_reduce_add((uint64_t)cnt);
+    __syncthreads();  // s_part reuse across segments
+    if (lane_id() == 0) s_part[threadIdx.x / kWave] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t t = 0;
+#pragma unroll
+      for (int i = 0; i < kBlock / kWave; ++i) t += s_part[i];
+      seg_count[seg] = t;
+    }
+  }
+}
+
+// One workgroup per batch: exclusive scan of that batch's segment counts.
+__global__ __launch_bounds__(kBlock) void k_filter_segscan(ColView sv, const uint32_t* seg_count,
+                                                           uint64_t* seg_base) {
+  __shared__ uint64_t s_wave[kBlock / kWave];
+  __shared__ uint64_t s_carry;
+  for (uint32_t b = blockIdx.x; b < sv.nb; b += gridDim.x) {
+    const uint64_t s0 = sv.units_per_batch ? (uint64_t)b * sv.units_per_batch : sv.unit_start[b];
+    const uint64_t s1 = sv.units_per_batch ? s0 + sv.units_per_batch : sv.unit_start[b + 1];
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (uint64_t base = s0; base < s1; base += kBlock) {
+      const uint64_t i = base + threadIdx.x;
+      uint64_t c = i < s1 ? seg_count[i] : 0;
+      uint64_t incl = c;  // inclusive wave scan
+#pragma unroll
+      for (int o = 1; o < kWave; o <<= 1) {
+        uint64_t y = __shfl_up(incl, o, kWave);
+        if ((int)lane_id() >= o) incl += y;
+      }
+      if (lane_id() == kWave - 1) s_wave[threadIdx.x / kWave] = incl;
+      __syncthreads();
+      uint64_t off = s_carry;
+      for (unsigned w = 0; w < threadIdx.x / kWave; ++w) off += s_wave[w];
+      if (i < s1) seg_base[i] = off + incl - c;
+      __syncthreads();
+      if (threadIdx.x == kBlock - 1) s_carry = off + incl;
+      __syncthreads();
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_filter_compact(ColView sv, const void* const* in_ptrs,
+                                                           void* const* out_ptrs, T thr,
+                                                           const uint64_t* seg_base,
+                                                           unsigned long long* out_rows) {
+  constexpr int E = 16 / sizeof(T);
+  constexpr uint32_t TILE = kBlock * kVecPerThread * E;
+  constexpr int NW = kBlock / kWave;
+  __shared__ uint32_t s_tot[2][kVecPerThread][NW];
+  const unsigned lane = lane_id();
+  const unsigned wave = threadIdx.x / kWave;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  int buf = 0;
+  for (uint64_t seg = blockIdx.x; seg < sv.total_units; seg += gridDim.x) {
+    Loc l = locate(sv, seg);
+    const uint64_t rows = batch_rows(sv, l.batch);
+    const uint64_t r0 = l.local_unit * sv.unit_rows;
+    const uint32_t n_seg = (uint32_t)min((uint64_t)sv.unit_rows, rows - r0);
+    const T* in = (const T*)in_ptrs[l.batch] + r0;
+    T* out = (T*)out_ptrs[l.batch];
+    const bool aligned = (((uintptr_t)in) & 15) == 0;
+    uint64_t base = seg_base ? seg_base[seg] : 0;
+    for (uint32_t t0 = 0; t0 < n_seg; t0 += TILE) {
+      const uint32_t n = min(TILE, n_seg - t0);
+      T val[kVecPerThread][E];
+      uint32_t flags[kVecPerThread];
+      filter_tile_flags<T>(in + t0, n, TILE, aligned && n == TILE, thr, val, flags);
+      uint32_t rank[kVecPerThread];
+#pragma unroll
+      for (int j = 0; j < kVecPerThread; ++j) {
+        const uint32_t c = __popc(flags[j]);
+        uint32_t r = 0, tot = 0;
+#pragma unroll
+        for (int bit = 0; bit < 3; ++bit) {  // c <= 4 -> three bit planes
+          const unsigned long long m = __ballot((c >> bit) & 1u);
+          r += (uint32_t)__popcll(m & lt_mask) << bit;
+          tot += (uint32_t)__popcll(m) << bit;
+        }
+        rank[j] = r;
+        if (lane == 0) s_tot[buf][j][wave] = tot;
+      }
+      __syncthreads();
+      uint32_t tile_total = 0;
+      uint32_t my_off[kVecPerThread];
+#pragma unroll
+      for (int j = 0; j < kVecPerThread; ++j) {
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+          if ((unsigned)w == wave) my_off[j] = tile_total;
+          tile_total += s_tot[buf][j][w];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < kVecPerThread; ++j) {
+        uint64_t o = base + my_off[j] + rank[j];
+#pragma unroll
+        for (int k = 0; k < E; ++k) {
+          if (flags[j] & (1u << k)) out[o++] = val[j][k];
+        }
+      }
+      base += tile_total;
+      buf ^= 1;  // double-buffered totals: one barrier per tile
+    }
+    const bool last_seg = (l.local_unit + 1) * (uint64_t)sv.unit_rows >= rows;
+    if (last_seg && threadIdx.x == 0) out_rows[l.batch] = base;
+  }
+}
+
+// ----------------------------------------------------------------- take
+// Tiles over the index stream of each batch; indices loaded 16 B per lane,
+// values gathered (the batch's data buffer is L2 / Infinity-Cache resident while
+// its tiles are in flight), results stored 16 B per lane.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_take(ColView iv, const void* const* data_ptrs,
+                                                 const void* const* idx_ptrs, void* const* out_ptrs) {
+  constexpr uint32_t TILE = kBlock * kVecPerThread * 4;  // indices per tile
+  for (uint64_t tile = blockIdx.x; tile < iv.total_units; tile += gridDim.x) {
+    Loc l = locate(iv, tile);
+    const uint64_t rows = batch_rows(iv, l.batch);
+    const uint64_t r0 = l.local_unit * TILE;
+    const uint32_t n = (uint32_t)min((uint64_t)TILE, rows - r0);
+    const uint32_t* idx = (const uint32_t*)idx_ptrs[l.batch] + r0;
+    const T* data = (const T*)data_ptrs[l.batch];
+    T* out = (T*)out_ptrs[l.batch] + r0;
+    if (n == TILE && (((uintptr_t)idx) & 15) == 0 && (((uintptr_t)out) & 15) == 0) {
+      uint4 ix[kVecPerThread];
+#pragma unroll
+      for (int j = 0; j < kVecPerThread; ++j) ix[j] = ((const uint4*)idx)[j * kBlock + threadIdx.x];
+      T g[kVecPerThread][4];
+#pragma unroll
+      for (int j = 0; j < kVecPerThread; ++j) {
+        g[j][0] = data[ix[j].x];
+        g[j][1] = data[ix[j].y];
+        g[j][2] = data[ix[j].z];
+        g[j][3] = data[ix[j].w];
+      }
+#pragma unroll
+      for (int j = 0; j < kVecPerThread; ++j) {
+        T* o = out + (size_t)(j * kBlock + threadIdx.x) * 4;
+        if constexpr (sizeof(T) == 4) {
+          *(uint4*)o = make_uint4((uint32_t)g[j][0], (uint32_t)g[j][1], (uint32_t)g[j][2], (uint32_t)g[j][3]);
+        } else {
+          ((ulonglong2*)o)[0] = make_ulonglong2((uint64_t)g[j][0], (uint64_t)g[j][1]);
+          ((ulonglong2*)o)[1] = make_ulonglong2((uint64_t)g[j][2], (uint64_t)g[j][3]);
+        }
+      }
+    } else {
+      for (uint32_t i = threadIdx.x; i < n; i += kBlock) out[i] = data[idx[i]];
+    }
+  }
+}
+
+static int grid_for(const olap_ctx* ctx, uint64_t units, int blocks_per_cu) {
+  uint64_t cap = (uint64_t)ctx->compute_units * blocks_per_cu;
+  uint64_t g = units < cap ? units : cap;
+  return (int)(g ? g : 1);
+}
+
+// Splits [0, nb) into chunks of batches whose staged bytes fit `budget`.
+static uint64_t next_chunk(const uint64_t* rows, uint64_t nb, uint64_t b0, uint64_t bytes_per_row,
+                           uint64_t budget) {
+  uint64_t b = b0, acc = 0;
+  while (b < nb) {
+    uint64_t add = rows[b] * bytes_per_row + 512;
+    if (b > b0 && acc + add > budget) break;
+    acc += add;
+    ++b;
+  }
+  return b;
+}
+
+constexpr uint64_t kHostChunkBudget = 1ull << 30;  // staging bytes per round for host inputs
+
+template <typename T, typename ACC>
+static int run_sum(olap_ctx* ctx, const void* const* ptrs, const uint64_t* rows, uint64_t nb, int in_mem,
+                   uint64_t* out_sum) {
+  constexpr uint32_t TILE = kTileBytes / sizeof(T);
+  const uint32_t eb = sizeof(T);
+  unsigned long long total = 0;
+  uint64_t b0 = 0;
+  while (b0 < nb) {
+    const uint64_t b1 = in_mem == OLAP_MEM_HOST ? next_chunk(rows, nb, b0, eb, kHostChunkBudget) : nb;
+    const uint64_t cnt = b1 - b0;
+    const void* const* cols[1] = {ptrs + b0};
+    OLAP_TRY(pinned_begin(ctx, (cnt + 1) * 8 * 3 + 4096));
+    OLAP_TRY(ws_begin(ctx, column_set_bytes(rows + b0, cnt, 1, &eb, in_mem) + 4096));
+    ColumnSet cs;
+    OLAP_TRY(build_column_set(ctx, cols, 1, &eb, rows + b0, cnt, in_mem, TILE, &cs));
+    unsigned long long* d_out = (unsigned long long*)ws_alloc(ctx, 8);
+    if (!d_out) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted");
+    OLAP_HIP(ctx, hipMemsetAsync(d_out, 0, 8, ctx->stream));
+    if (cs.view.total_units) {
+      PhaseScope ps(ctx, PH_SUM);
+      hipLaunchKernelGGL((k_sum<T, ACC>), dim3(grid_for(ctx, cs.view.total_units, 8)), dim3(kBlock), 0,
+                         ctx->stream, cs.view, cs.dev_ptr_tables[0], d_out);
+      OLAP_HIP(ctx, hipGetLastError());
+    }
+    unsigned long long part = 0;
+    OLAP_HIP(ctx, hipMemcpyAsync(&part, d_out, 8, hipMemcpyDeviceToHost, ctx->stream));
+    OLAP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    total += part;  // host add of the per-round partials (host/aggr/aggr_dpu.cc:82-84)
+    b0 = b1;
+  }
+  *out_sum = total;
+  return resolve_timers(ctx);
+}
+
+template <typename T>
+static int run_filter(olap_ctx* ctx, const void* const* ptrs, const uint64_t* rows, uint64_t nb, int in_mem,
+                      const void* threshold, void* const* out_ptrs, int out_mem, uint64_t* out_rows,
+                      uint64_t* out_total) {
+  constexpr uint32_t TILE = kTileBytes / sizeof(T);
+  const uint32_t eb = sizeof(T);
+  T thr;
+  std::memcpy(&thr, threshold, sizeof(T));
+  uint64_t grand = 0;
+  uint64_t b0 = 0;
+  while (b0 < nb) {
+    const bool staged = in_mem == OLAP_MEM_HOST || out_mem == OLAP_MEM_HOST;
+    const uint64_t b1 = staged ? next_chunk(rows, nb, b0, 2 * eb, kHostChunkBudget) : nb;
+    const uint64_t cnt = b1 - b0;
+    uint64_t total_rows = 0, max_rows = 0;
+    for (uint64_t b = b0; b < b1; ++b) {
+      total_rows += rows[b];
+      if (rows[b] > max_rows) max_rows = rows[b];
+    }
+    // segment size: a multiple of the tile; whole 64 Ki-row batches stay one segment
+    uint32_t seg_rows = 16 * TILE;
+    const uint64_t want_units = (uint64_t)ctx->compute_units * 8;
+    if (cnt < want_units && total_rows / want_units < seg_rows) {
+      uint64_t s = total_rows / want_units;
+      s = align_up(s ? s : 1, TILE);
+      seg_rows = (uint32_t)(s < TILE ? TILE : (s > 16 * TILE ? 16 * TILE : s));
+    }
+    const bool multi_seg = max_rows > seg_rows;
+    const void* const* cols[1] = {ptrs + b0};
+    uint64_t n_seg_est = 0;
+    for (uint64_t b = b0; b < b1; ++b) n_seg_est += (rows[b] + seg_rows - 1) / seg_rows;
+    uint64_t need = column_set_bytes(rows + b0, cnt, 1, &eb, in_mem) + align_up(cnt * 8, 256) * 3 +
+                    align_up(n_seg_est * 12, 256) * 2 + 8192;
+    if (out_mem == OLAP_MEM_HOST) {
+      for (uint64_t b = b0; b < b1; ++b) need += align_up(rows[b] * eb, 256);
+    }
+    OLAP_TRY(pinned_begin(ctx, (cnt + 1) * 8 * 6 + 4096));
+    OLAP_TRY(ws_begin(ctx, need));
+    ColumnSet cs;
+    OLAP_TRY(build_column_set(ctx, cols, 1, &eb, rows + b0, cnt, in_mem, seg_rows, &cs));
+    // output pointer table
+    void** h_out = (void**)pinned_alloc(ctx, (cnt ? cnt : 1) * 8);
+    void** d_out_tbl = (void**)ws_alloc(ctx, (cnt ? cnt : 1) * 8);
+    unsigned long long* d_rows = (unsigned long long*)ws_alloc(ctx, (cnt ? cnt : 1) * 8);
+    unsigned long long* h_rows = (unsigned long long*)pinned_alloc(ctx, (cnt ? cnt : 1) * 8);
+    if (!h_out || !d_out_tbl || !d_rows || !h_rows) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted");
+    for (uint64_t b = 0; b < cnt; ++b) {
+      if (out_mem == OLAP_MEM_HOST) {
+        h_out[b] = ws_alloc(ctx, rows[b0 + b] * eb ? rows[b0 + b] * eb : 1);
+        if (!h_out[b]) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (filter output staging)");
+      } else {
+        if (rows[b0 + b] && !out_ptrs[b0 + b]) return ctx->fail(OLAP_ERR_INVALID, "null output pointer");
+        if (((uintptr_t)out_ptrs[b0 + b]) % eb) return ctx->fail(OLAP_ERR_INVALID, "output pointer misaligned");
+        h_out[b] = out_ptrs[b0 + b];
+      }
+    }
+    OLAP_HIP(ctx, hipMemcpyAsync(d_out_tbl, h_out, (cnt ? cnt : 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    OLAP_HIP(ctx, hipMemsetAsync(d_rows, 0, (cnt ? cnt : 1) * 8, ctx->stream));
+    uint64_t* d_seg_base = nullptr;
+    if (cs.view.total_units) {
+      const int grid = grid_for(ctx, cs.view.total_units, 8);
+      if (multi_seg) {
+        uint32_t* d_seg_count = (uint32_t*)ws_alloc(ctx, cs.view.total_units * 4);
+        d_seg_base = (uint64_t*)ws_alloc(ctx, cs.view.total_units * 8);
+        if (!d_seg_count || !d_seg_base) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (segments)");
+        {
+          PhaseScope ps(ctx, PH_FILTER_COUNT);
+          hipLaunchKernelGGL((k_filter_count<T>), dim3(grid), dim3(kBlock), 0, ctx->stream, cs.view,
+                             cs.dev_ptr_tables[0], thr, d_seg_count);
+          hipLaunchKernelGGL(k_filter_segscan, dim3(grid_for(ctx, cnt, 8)), dim3(kBlock), 0, ctx->stream,
+                             cs.view, d_seg_count, d_seg_base);
+          OLAP_HIP(ctx, hipGetLastError());
+        }
+      }
+      PhaseScope ps(ctx, PH_FILTER_COMPACT);
+      hipLaunchKernelGGL((k_filter_compact<T>), dim3(grid), dim3(kBlock), 0, ctx->stream, cs.view,
+                         cs.dev_ptr_tables[0], (void* const*)d_out_tbl, thr, (const uint64_t*)d_seg_base, d_rows);
+      OLAP_HIP(ctx, hipGetLastError());
+    }
+    OLAP_HIP(ctx, hipMemcpyAsync(h_rows, d_rows, (cnt ? cnt : 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    OLAP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (uint64_t b = 0; b < cnt; ++b) {
+      out_rows[b0 + b] = h_rows[b];
+      grand += h_rows[b];
+    }
+    if (out_mem == OLAP_MEM_HOST) {
+      PhaseScope ps(ctx, PH_COPY_FROM);
+      for (uint64_t b = 0; b < cnt; ++b) {
+        if (h_rows[b])
+          OLAP_HIP(ctx, hipMemcpyAsync(out_ptrs[b0 + b], h_out[b], h_rows[b] * eb, hipMemcpyDeviceToHost, ctx->stream));
+      }
+    }
+    OLAP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    b0 = b1;
+  }
+  if (out_total) *out_total = grand;
+  return resolve_timers(ctx);
+}
+
+template <typename T>
+static int run_take(olap_ctx* ctx, const void* const* data_ptrs, const uint64_t* data_rows,
+                    const uint32_t* const* idx_ptrs, const uint64_t* idx_rows, uint64_t nb, int in_mem,
+                    void* const* out_ptrs, int out_mem) {
+  constexpr uint32_t TILE = kBlock * kVecPerThread * 4;
+  const uint32_t eb = sizeof(T), ib = 4;
+  uint64_t b0 = 0;
+  while (b0 < nb) {
+    uint64_t b1 = nb;
+    const bool staged = in_mem == OLAP_MEM_HOST || out_mem == OLAP_MEM_HOST;
+    if (staged) {  // chunk by data + idx + out bytes
+      uint64_t acc = 0;
+      b1 = b0;
+      while (b1 < nb) {
+        uint64_t add = data_rows[b1] * eb + idx_rows[b1] * (4 + eb) + 1024;
+        if (b1 > b0 && acc + add > kHostChunkBudget) break;
+        acc += add;
+        ++b1;
+      }
+    }
+    const uint64_t cnt = b1 - b0;
+    const void* const* dcols[1] = {data_ptrs + b0};
+    const void* const* icols[1] = {(const void* const*)(idx_ptrs + b0)};
+    uint64_t need = column_set_bytes(data_rows + b0, cnt, 1, &eb, in_mem) +
+                    column_set_bytes(idx_rows + b0, cnt, 1, &ib, in_mem) + align_up(cnt * 8, 256) + 8192;
+    if (out_mem == OLAP_MEM_HOST)
+      for (uint64_t b = b0; b < b1; ++b) need += align_up(idx_rows[b] * eb, 256);
+    OLAP_TRY(pinned_begin(ctx, (cnt + 1) * 8 * 8 + 4096));
+    OLAP_TRY(ws_begin(ctx, need));
+    ColumnSet ds, is;
+    OLAP_TRY(build_column_set(ctx, dcols, 1, &eb, data_rows + b0, cnt, in_mem, TILE, &ds));
+    OLAP_TRY(build_column_set(ctx, icols, 1, &ib, idx_rows + b0, cnt, in_mem, TILE, &is));
+    void** h_out = (void**)pinned_alloc(ctx, (cnt ? cnt : 1) * 8);
+    void** d_out_tbl = (void**)ws_alloc(ctx, (cnt ? cnt : 1) * 8);
+    if (!h_out || !d_out_tbl) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted");
+    for (uint64_t b = 0; b < cnt; ++b) {
+      if (out_mem == OLAP_MEM_HOST) {
+        h_out[b] = ws_alloc(ctx, idx_rows[b0 + b] * eb ? idx_rows[b0 + b] * eb : 1);
+        if (!h_out[b]) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (take output staging)");
+      } else {
+        if (idx_rows[b0 + b] && !out_ptrs[b0 + b]) return ctx->fail(OLAP_ERR_INVALID, "null output pointer");
+        if (((uintptr_t)out_ptrs[b0 + b]) % eb) return ctx->fail(OLAP_ERR_INVALID, "output pointer misaligned");
+        h_out[b] = out_ptrs[b0 + b];
+      }
+    }
+    OLAP_HIP(ctx, hipMemcpyAsync(d_out_tbl, h_out, (cnt ? cnt : 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (is.view.total_units) {
+      PhaseScope ps(ctx, PH_TAKE);
+      hipLaunchKernelGGL((k_take<T>), dim3(grid_for(ctx, is.view.total_units, 8)), dim3(kBlock), 0, ctx->stream,
+                         is.view, ds.dev_ptr_tables[0], is.dev_ptr_tables[0], (void* const*)d_out_tbl);
+      OLAP_HIP(ctx, hipGetLastError());
+    }
+    if (out_mem == OLAP_MEM_HOST) {
+      PhaseScope ps(ctx, PH_COPY_FROM);
+      for (uint64_t b = 0; b < cnt; ++b) {
+        if (idx_rows[b0 + b])
+          OLAP_HIP(ctx, hipMemcpyAsync(out_ptrs[b0 + b], h_out[b], idx_rows[b0 + b] * eb, hipMemcpyDeviceToHost, ctx->stream));
+      }
+    }
+    OLAP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    b0 = b1;
+  }
+  return resolve_timers(ctx);
+}
+
+static int check_common(olap_ctx* ctx, int dtype, const void* p, const uint64_t* rows, uint64_t nb, int mem) {
+  if (!ctx) return OLAP_ERR_INVALID;
+  if (!dtype_ok(dtype)) return ctx->fail(OLAP_ERR_INVALID, "unknown dtype %d", dtype);
+  if (nb && (!p || !rows)) return ctx->fail(OLAP_ERR_INVALID, "null batch table");
+  if (mem != OLAP_MEM_HOST && mem != OLAP_MEM_DEVICE) return ctx->fail(OLAP_ERR_INVALID, "bad memory space %d", mem);
+  if (hipSetDevice(ctx->device) != hipSuccess) return ctx->fail(OLAP_ERR_DEVICE, "hipSetDevice failed");
+  return OLAP_OK;
+}
+
+}  // namespace olap
+
+using namespace olap;
+
+extern "C" {
+
+int olap_sum(olap_ctx* ctx, int dtype, const void* const* ptrs, const uint64_t* rows, uint64_t n_batches,
+             int in_mem, uint64_t* out_sum) {
+  OLAP_TRY(check_common(ctx, dtype, ptrs, rows, n_batches, in_mem));
+  if (!out_sum) return ctx->fail(OLAP_ERR_INVALID, "out_sum is null");
+  switch (dtype) {
+    case OLAP_U32: return run_sum<uint32_t, unsigned long long>(ctx, ptrs, rows, n_batches, in_mem, out_sum);
+    case OLAP_I32: return run_sum<int32_t, long long>(ctx, ptrs, rows, n_batches, in_mem, out_sum);
+    case OLAP_U64: return run_sum<uint64_t, unsigned long long>(ctx, ptrs, rows, n_batches, in_mem, out_sum);
+    default: return run_sum<int64_t, unsigned long long>(ctx, ptrs, rows, n_batches, in_mem, out_sum);
+  }
+}
+
+int olap_filter_lt(olap_ctx* ctx, int dtype, const void* const* ptrs, const uint64_t* rows, uint64_t n_batches,
+                   int in_mem, const void* threshold, void* const* out_ptrs, int out_mem, uint64_t* out_rows,
+                   uint64_t* out_total) {
+  OLAP_TRY(check_common(ctx, dtype, ptrs, rows, n_batches, in_mem));
+  if (!threshold) return ctx->fail(OLAP_ERR_INVALID, "threshold is null");
+  if (n_batches && (!out_ptrs || !out_rows)) return ctx->fail(OLAP_ERR_INVALID, "null output table");
+  if (out_mem != OLAP_MEM_HOST && out_mem != OLAP_MEM_DEVICE) return ctx->fail(OLAP_ERR_INVALID, "bad out_mem");
+  switch (dtype) {
+    case OLAP_U32: return run_filter<uint32_t>(ctx, ptrs, rows, n_batches, in_mem, threshold, out_ptrs, out_mem, out_rows, out_total);
+    case OLAP_I32: return run_filter<int32_t>(ctx, ptrs, rows, n_batches, in_mem, threshold, out_ptrs, out_mem, out_rows, out_total);
+    case OLAP_U64: return run_filter<uint64_t>(ctx, ptrs, rows, n_batches, in_mem, threshold, out_ptrs, out_mem, out_rows, out_total);
+    default: return run_filter<int64_t>(ctx, ptrs, rows, n_batches, in_mem, threshold, out_ptrs, out_mem, out_rows, out_total);
+  }
+}
+
+int olap_take(olap_ctx* ctx, int dtype, const void* const* data_ptrs, const uint64_t* data_rows,
+              const uint32_t* const* idx_ptrs, const uint64_t* idx_rows, uint64_t n_batches, int in_mem,
+              void* const* out_ptrs, int out_mem) {
+  OLAP_TRY(check_common(ctx, dtype, data_ptrs, data_rows, n_batches, in_mem));
+  if (n_batches && (!idx_ptrs || !idx_rows || !out_ptrs)) return ctx->fail(OLAP_ERR_INVALID, "null index/output table");
+  if (out_mem != OLAP_MEM_HOST && out_mem != OLAP_MEM_DEVICE) return ctx->fail(OLAP_ERR_INVALID, "bad out_mem");
+  if (dtype_bytes(dtype) == 4)
+    return run_take<uint32_t>(ctx, data_ptrs, data_rows, idx_ptrs, idx_rows, n_batches, in_mem, out_ptrs, out_mem);
+  return run_take<uint64_t>(ctx, data_ptrs, data_rows, idx_ptrs, idx_rows, n_batches, in_mem, out_ptrs, out_mem);
+}
+
+}  // extern "C"

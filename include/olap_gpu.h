@@ -1,0 +1,221 @@
+/*
+ * olap_gpu.h -- C ABI of the MI355X (gfx950) operator hot path that replaces the
+ * UPMEM DPU path of upmem/dpu_olap: filter, take, sum-aggregate, radix partition
+ * and radix-partitioned PK-FK hash join over Arrow fixed-width integer columns.
+ *
+ * This header IS the drop-in boundary.  It replaces the reference's
+ * host<->device protocol, i.e. shared/umq/kernels.h:12-51 (`enum Kernel`, the
+ * per-kernel INPUT/OUTPUT structs) together with the libdpu calls that carry it
+ * (host/dpuext/dpuext.hpp:148-927, host/dpuext/arrow_utils.cc:25-266).  Where the
+ * reference addresses DPU memory by symbol name ("buffer", "output_buffer",
+ * "selection_indices_vector", "INPUT", "kernel") and launches one DPU program per
+ * operator (dpu/{filter,take,aggr,partition,join}/main.c), this ABI takes plain
+ * pointers and sizes and launches hand-written HIP kernels.
+ *
+ * Conventions
+ *  - Every function returns an olap_status (0 = ok, negative = error class) and
+ *    never throws or aborts (the reference: DpuError exceptions / DPU_ASSERT,
+ *    host/dpuext/dpuext.hpp:54-90, host/dpuext/status.h:7-11).  A message is
+ *    kept per context: olap_last_error().
+ *  - Columns are passed the way the reference's operators see them: a vector of
+ *    batches (arrow::RecordBatchVector), one contiguous data buffer per (batch,
+ *    column), no validity bitmap (all benchmark columns are non-nullable,
+ *    host/dpuext/arrow_utils.h:27-29).  `ptrs[b]` is the data buffer of batch b
+ *    (Arrow buffer index 1, host/dpuext/arrow_utils.cc:64-66), `rows[b]` its
+ *    length in elements.  The pointer/row TABLES are always host arrays; `mem`
+ *    says where the buffers they point to live.
+ *  - OLAP_MEM_DEVICE buffers must be 4-byte (32-bit types) / 8-byte (64-bit
+ *    types) aligned; 16-byte alignment takes the vector fast path.
+ *  - A context is single-caller (one host thread drives it); distinct contexts
+ *    are independent.  One context == one GPU.
+ *  - All calls are synchronous on return unless stated otherwise.
+ */
+#ifndef OLAP_GPU_H_
+#define OLAP_GPU_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OLAP_ABI_VERSION 1
+
+typedef struct olap_ctx olap_ctx;
+
+typedef enum {
+  OLAP_OK = 0,
+  OLAP_ERR_INVALID = -1,   /* bad argument */
+  OLAP_ERR_DEVICE = -2,    /* HIP runtime error (message has hipGetErrorString) */
+  OLAP_ERR_NOMEM = -3,     /* device / pinned allocation failed */
+  OLAP_ERR_NO_MATCH = -4,  /* join: a foreign key has no primary key (reference asserts, dpu/shared/kernels/hash_probe.c:32-33) */
+  OLAP_ERR_OVERFLOW = -5,  /* join: a final partition's build side exceeds the LDS table (reference: ht_put false -> assert, hash_build.c:30-31) */
+  OLAP_ERR_CAPACITY = -6   /* caller-provided output buffer too small */
+} olap_status;
+
+/* Element types (the reference hard-wires uint32_t, dpu/shared/kernels/common.h:3-4) */
+typedef enum { OLAP_U32 = 0, OLAP_I32 = 1, OLAP_U64 = 2, OLAP_I64 = 3 } olap_dtype;
+
+typedef enum { OLAP_MEM_HOST = 0, OLAP_MEM_DEVICE = 1 } olap_mem;
+
+/* ------------------------------------------------------------------ context
+ * Replaces dpu::DpuSet::allocate()/load() (host/dpuext/dpuext.hpp:709-715,
+ * 738-744): there is no program-load step, kernels are linked in. */
+int olap_abi_version(void);
+int olap_create(int device_id, olap_ctx** out_ctx);
+void olap_destroy(olap_ctx* ctx);
+const char* olap_last_error(const olap_ctx* ctx);
+/* name[] receives the device name; any out pointer may be NULL. */
+int olap_device_info(olap_ctx* ctx, char* name, size_t name_cap, int* compute_units,
+                     uint64_t* total_mem_bytes, uint64_t* free_mem_bytes);
+/* Run the context's kernels on a caller-owned hipStream_t (NULL = the context's
+ * own stream).  Lets a host runtime order our kernels with its own work. */
+int olap_set_stream(olap_ctx* ctx, void* hip_stream);
+void* olap_get_stream(olap_ctx* ctx);
+int olap_synchronize(olap_ctx* ctx);
+/* Pre-size the internal scratch arena (partition ping-pong buffers, histograms,
+ * staging).  Optional: the arena grows on demand.  Mirrors the role of
+ * Prepare() (host/join/join_dpu.cc:144-156). */
+int olap_reserve_workspace(olap_ctx* ctx, uint64_t bytes);
+uint64_t olap_workspace_bytes(const olap_ctx* ctx);
+
+/* -------------------------------------------------------- device memory
+ * For callers that keep columns resident in HBM (the benchmark harness).
+ * Replaces the static per-DPU MRAM buffers (dpu/filter/main.c:20-27). */
+int olap_malloc(olap_ctx* ctx, uint64_t bytes, void** out_dptr);
+int olap_free(olap_ctx* ctx, void* dptr);
+int olap_memcpy_h2d(olap_ctx* ctx, void* dst_device, const void* src_host, uint64_t bytes);
+int olap_memcpy_d2h(olap_ctx* ctx, void* dst_host, const void* src_device, uint64_t bytes);
+int olap_memset(olap_ctx* ctx, void* dst_device, int byte_value, uint64_t bytes);
+
+/* ------------------------------------------------------------------ timers
+ * Replaces timer::Timers (host/timer/timer.h:28-39; names copy-to-dpu, dpu-work,
+ * copy-from-dpu of host/filter/filter_dpu.cc:107-110 and the join phases of
+ * host/join/join_dpu.cc:146-148).  With profiling on, every kernel launch is
+ * bracketed by HIP events on the context's stream; the accumulated device time
+ * and launch count per phase are returned.  Phase names: "copy-to-gpu",
+ * "copy-from-gpu", "sum", "filter-count", "filter-compact", "take",
+ * "partition-hist", "partition-scan", "partition-scatter", "join-probe", "gen". */
+int olap_set_profiling(olap_ctx* ctx, int enabled);
+int olap_reset_timers(olap_ctx* ctx);
+/* Fills up to `cap` entries; *out_n = number of phases with launches. names[i]
+ * points to static storage. */
+int olap_get_timers(olap_ctx* ctx, const char** names, double* total_ms, uint64_t* launches,
+                    int cap, int* out_n);
+
+/* ------------------------------------------------------------------ filter
+ * Replaces kernel_filter (dpu/shared/kernels/filter.c:57-177, predicate :25) and
+ * FilterDpu::GetResult's per-DPU result pull (host/filter/filter_dpu.cc:50-101).
+ * For every batch b: out_ptrs[b][0 .. out_rows[b]) = the values v of batch b with
+ * v < *threshold (compared in `dtype`, so unsigned for U32/U64), input order
+ * preserved.  out_ptrs[b] must have room for rows[b] elements (worst case, as the
+ * reference sizes its transfer, filter_dpu.cc:67-83) and lives in `out_mem`.
+ * out_rows (host array, n_batches) and *out_total (may be NULL) are filled. */
+int olap_filter_lt(olap_ctx* ctx, int dtype, const void* const* ptrs, const uint64_t* rows,
+                   uint64_t n_batches, int in_mem, const void* threshold, void* const* out_ptrs,
+                   int out_mem, uint64_t* out_rows, uint64_t* out_total);
+
+/* --------------------------------------------------------------------- sum
+ * Replaces kernel_aggr + sum (dpu/shared/kernels/aggr.c:16-33,
+ * dpu/aggr/main.c:44-50,76-88) and the host add (host/aggr/aggr_dpu.cc:82-84).
+ * U32 -> uint64 sum, I32 -> int64 sum, U64/I64 wrap mod 2^64 (Arrow "sum"
+ * semantics).  The 64-bit result bit pattern is stored in *out_sum. */
+int olap_sum(olap_ctx* ctx, int dtype, const void* const* ptrs, const uint64_t* rows,
+             uint64_t n_batches, int in_mem, uint64_t* out_sum);
+
+/* -------------------------------------------------------------------- take
+ * Replaces kernel_take (dpu/shared/kernels/take.c:12-47, params
+ * shared/umq/kernels.h:39-42): for every batch b and i < idx_rows[b]:
+ *   out_ptrs[b][i] = data_ptrs[b][ idx_ptrs[b][i] ]      (uint32 indices)
+ * No bounds check, like the reference (take.c:36) and TakeNative's
+ * NoBoundsCheck (host/take/take_native.cc:27).  dtype gives the data width. */
+int olap_take(olap_ctx* ctx, int dtype, const void* const* data_ptrs, const uint64_t* data_rows,
+              const uint32_t* const* idx_ptrs, const uint64_t* idx_rows, uint64_t n_batches,
+              int in_mem, void* const* out_ptrs, int out_mem);
+
+/* --------------------------------------------------------------- partition
+ * Replaces kernel_partition (dpu/shared/kernels/partition.c:296-341, params
+ * shared/umq/kernels.h:27-37), the payload re-gather (Partitioner::TakeKernel,
+ * host/partition/partitioner.cc:185-207) and the shuffle (GetOffsets /
+ * LoadPartitions, partitioner.cc:280-375) in one device-side step.
+ * Tuples (key, payload) of all batches are grouped by
+ *   bucket = wang_hash(key) >> (32 - log2(nr_partitions))   (partition.c:45-46)
+ * into out_keys / out_payload (contiguous, capacity `out_capacity` rows, in
+ * out_mem); out_offsets (host, nr_partitions + 1) receives the start of every
+ * partition (out_offsets[p+1] is the END offset the reference calls metadata,
+ * host/join/join_dpu.cc:54-66).  Order inside a partition is unspecified, as in
+ * the reference.  nr_partitions: power of two, 2 .. 2^20.  payload_ptrs may be
+ * NULL (keys only; out_payload then receives the global row index). */
+int olap_partition_u32(olap_ctx* ctx, const uint32_t* const* key_ptrs,
+                       const uint32_t* const* payload_ptrs, const uint64_t* rows,
+                       uint64_t n_batches, int in_mem, uint32_t nr_partitions, uint32_t* out_keys,
+                       uint32_t* out_payload, uint64_t out_capacity, int out_mem,
+                       uint64_t* out_offsets);
+
+/* -------------------------------------------------------------------- join
+ * Replaces JoinDpu::Run_internal (host/join/join_dpu.cc:168-400): radix
+ * partition of both tables, then per partition kernel_hash_build
+ * (dpu/shared/kernels/hash_build.c:9-35) on the right key, kernel_hash_probe
+ * (hash_probe.c:9-46) with the left key and the take of the right payload.
+ * left = {fk, y}, right = {pk, x}; output rows {fk, y, x} (left columns then the
+ * right non-key column, join_dpu.cc:314-363), partition-major, order inside a
+ * partition unspecified (tests sort, host/join/join_test.cc:27-38).
+ * Contract of the reference kept: pk unique (a duplicate overwrites,
+ * hashtable.c:133 -- counted in stats), every fk has a match (else
+ * OLAP_ERR_NO_MATCH).  out_* have capacity `out_capacity` >= total left rows. */
+typedef struct {
+  uint32_t passes;           /* radix passes run per side */
+  uint32_t radix_bits[4];    /* bits per pass */
+  uint32_t nr_partitions;    /* final partitions = 2^sum(bits) */
+  uint32_t table_slots;      /* LDS hash table slots per partition */
+  uint64_t left_rows, right_rows;
+  uint64_t max_build_rows;   /* largest final build partition */
+  uint64_t duplicate_keys;   /* build keys that overwrote an equal key */
+  uint64_t missing_keys;     /* probe keys without a match */
+} olap_join_stats;
+
+int olap_join_u32(olap_ctx* ctx, const uint32_t* const* left_fk_ptrs,
+                  const uint32_t* const* left_y_ptrs, const uint64_t* left_rows,
+                  uint64_t n_left_batches, const uint32_t* const* right_pk_ptrs,
+                  const uint32_t* const* right_x_ptrs, const uint64_t* right_rows,
+                  uint64_t n_right_batches, int in_mem, uint32_t* out_fk, uint32_t* out_y,
+                  uint32_t* out_x, uint64_t out_capacity, int out_mem, uint64_t* out_rows,
+                  olap_join_stats* stats /* may be NULL */);
+
+/* Tuning knobs (0 = default).  radix_bits_total < 0 keeps the automatic choice
+ * ceil(log2(right_rows / 4096)). */
+int olap_join_configure(olap_ctx* ctx, int radix_bits_total, int max_bits_per_pass);
+
+/* --------------------------------------------------------------- generator
+ * Synthetic columns with the distributions of host/generator/generator.cc:22-71
+ * (uniform u32 payloads, pk = 0,1,2,..., fk of left batch i uniform in
+ * [i*R, (i+1)*R-1]).  Counter based: element at global row r of stream s is
+ *   mix32(seed, s, r)   (see dpu_olap_amd/datagen.py for the host mirror)
+ * so SF=2048 columns are produced in HBM and any slice can be re-derived. */
+int olap_gen_uniform_u32(olap_ctx* ctx, uint32_t* out_device, uint64_t n, uint64_t seed,
+                         uint32_t stream_id, uint64_t first_row);
+int olap_gen_uniform_u64(olap_ctx* ctx, uint64_t* out_device, uint64_t n, uint64_t seed,
+                         uint32_t stream_id, uint64_t first_row);
+int olap_gen_index_u32(olap_ctx* ctx, uint32_t* out_device, uint64_t n, uint32_t first_value);
+/* out[r - first_row] = (r / left_batch_rows) * right_batch_rows
+ *                      + mix32(seed, stream, r) mod right_batch_rows (multiply-high) */
+int olap_gen_fk_u32(olap_ctx* ctx, uint32_t* out_device, uint64_t n, uint64_t seed,
+                    uint32_t stream_id, uint64_t first_row, uint64_t left_batch_rows,
+                    uint64_t right_batch_rows);
+/* out[i] = mix32(seed, stream, rows[i])  -- the generator evaluated at given row ids */
+int olap_gen_uniform_u32_at(olap_ctx* ctx, uint32_t* out_device, const uint32_t* rows_device,
+                            uint64_t n, uint64_t seed, uint32_t stream_id);
+/* Order-independent digest of a device column: sum, xor and sum of mix64 of the
+ * elements, all mod 2^64 (out[0..2]).  elem_bytes 4 or 8. */
+int olap_checksum(olap_ctx* ctx, const void* col_device, uint64_t n, int elem_bytes,
+                  uint64_t out[3]);
+/* Digest of the rows of a 3-column u32 table, independent of row order:
+ * out[0] = sum_i mix64(a_i, b_i, c_i), out[1] = xor_i of the same. */
+int olap_checksum_rows3_u32(olap_ctx* ctx, const uint32_t* a, const uint32_t* b,
+                            const uint32_t* c, uint64_t n, uint64_t out[2]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OLAP_GPU_H_ */

@@ -1,0 +1,388 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C
+ABI (include/olap_gpu.h via dpu_olap_amd.capi), against the CPU oracle, the
+reference's known-answer data and the Arrow golden vectors.  Bit-exact for all
+integer / index work."""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import sort_rows, split_batches
+
+pytestmark = pytest.mark.gpu
+
+TYPES = {"u32": np.uint32, "i32": np.int32, "u64": np.uint64, "i64": np.int64}
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from dpu_olap_amd import Device
+    d = Device(0)
+    yield d
+    d.close()
+
+
+def _ops():
+    import dpu_olap_amd
+    return dpu_olap_amd
+
+
+# ----------------------------------------------------------------- filter
+def test_filter_reference_kats(dev, kats, golden):
+    o = _ops()
+    small = np.array(kats["small_column"], dtype=np.uint32)
+    f = o.FilterGpu(dev, [small]).Prepare()
+    assert f.Run() == kats["filter_simple_test"]["expected_count"]  # FilterTest.SimpleTest
+    frt = kats["filter_result_test"]
+    pat = np.arange(frt["rows"], dtype=np.uint32) + np.uint32(1 << 30)
+    for i in frt["small_positions"]:
+        pat[i] = i
+    res = o.FilterGpu(dev, [pat]).Prepare().GetResult()  # FilterTest.ResultTest
+    np.testing.assert_array_equal(res[0], np.array(frt["expected"], dtype=np.uint32))
+    res = o.FilterGpu(dev, [golden["edge_u32_in"]]).Prepare().GetResult()
+    np.testing.assert_array_equal(res[0], golden["edge_u32_out"])  # unsigned compare
+
+
+@pytest.mark.parametrize("t", list(TYPES))
+@pytest.mark.parametrize("space", ["host", "device"])
+def test_filter_vs_arrow_golden(dev, golden, t, space):
+    o = _ops()
+    batches = split_batches(golden[f"rand_{t}_values"], golden[f"rand_{t}_sizes"])
+    thr = golden[f"rand_{t}_thr"][0].item()
+    ins = batches if space == "host" else [dev.to_device(b) for b in batches]
+    res = o.FilterGpu(dev, ins, threshold=thr).Prepare().GetResult()
+    if space == "device":
+        res = [dev.to_host(r) for r in res]
+    np.testing.assert_array_equal(np.array([r.size for r in res], dtype=np.uint64), golden[f"rand_{t}_filter_counts"])
+    np.testing.assert_array_equal(np.concatenate(res), golden[f"rand_{t}_filter_out"])
+
+
+@pytest.mark.parametrize("rows", [1, 4095, 4096, 4097, 65536, 65537, 1 << 20, (1 << 22) + 13])
+def test_filter_single_batch_sizes_vs_oracle(dev, rows):
+    """FilterTest.LongerTest shape (1 x 64Ki) and the multi-segment path (batch longer
+    than one segment -> count + scan + compact)."""
+    o = _ops()
+    rng = np.random.default_rng(rows)
+    v = rng.integers(0, 1 << 32, size=rows, dtype=np.uint32)
+    res = o.FilterGpu(dev, [v]).Prepare().GetResult()
+    np.testing.assert_array_equal(res[0], oracle.filter_lt(v, 1 << 30))
+
+
+def test_filter_many_batches_device_and_unaligned(dev):
+    o = _ops()
+    rng = np.random.default_rng(7)
+    nb, rows = 128, 65536
+    v = rng.integers(0, 1 << 32, size=nb * rows + 3, dtype=np.uint32)
+    d = dev.to_device(v)
+    # aligned batches
+    ins = [o.DeviceArray(d.ptr + 4 * b * rows, rows, "uint32") for b in range(nb)]
+    res = o.FilterGpu(dev, ins).Prepare().GetResult()
+    for b in (0, 1, 63, 127):
+        np.testing.assert_array_equal(dev.to_host(res[b]), oracle.filter_lt(v[b * rows:(b + 1) * rows], 1 << 30))
+    total = sum(r.rows for r in res)
+    assert total == oracle.filter_lt(v[: nb * rows], 1 << 30).size
+    # 4-byte aligned only (Arrow slices): scalar path
+    ins = [o.DeviceArray(d.ptr + 4 * (b * rows + 1), rows, "uint32") for b in range(4)]
+    res = o.FilterGpu(dev, ins).Prepare().GetResult()
+    for b in range(4):
+        np.testing.assert_array_equal(dev.to_host(res[b]), oracle.filter_lt(v[b * rows + 1:(b + 1) * rows + 1], 1 << 30))
+
+
+def test_filter_empty_inputs(dev):
+    o = _ops()
+    assert o.FilterGpu(dev, []).Prepare().Run() == 0
+    res = o.FilterGpu(dev, [np.empty(0, np.uint32), np.array([1], np.uint32)]).Prepare().GetResult()
+    assert res[0].size == 0 and res[1].tolist() == [1]
+
+
+# -------------------------------------------------------------------- sum
+def test_sum_reference_kat(dev, kats):
+    o = _ops()
+    small = np.array(kats["small_column"], dtype=np.uint32)
+    assert o.SumGpu(dev, [small]).Prepare().Run() == kats["sum_simple_test"]["expected"]
+
+
+@pytest.mark.parametrize("t", list(TYPES))
+@pytest.mark.parametrize("space", ["host", "device"])
+def test_sum_vs_arrow_golden(dev, golden, t, space):
+    o = _ops()
+    batches = split_batches(golden[f"rand_{t}_values"], golden[f"rand_{t}_sizes"])
+    ins = batches if space == "host" else [dev.to_device(b) for b in batches]
+    assert o.SumGpu(dev, ins).Prepare().Run() == int(golden[f"rand_{t}_sum"][0])
+
+
+def test_sum_large_and_wrap(dev):
+    """SumTest.LargeTest shape: 128 x 64Ki random u32; plus u64/i64 wrap like Arrow."""
+    o = _ops()
+    rng = np.random.default_rng(42)
+    batches = [rng.integers(0, 1 << 32, size=65536, dtype=np.uint32) for _ in range(128)]
+    assert o.SumGpu(dev, batches).Prepare().Run() == sum(oracle.sum_(b) for b in batches)
+    assert o.SumGpu(dev, [np.array([(1 << 64) - 1, 5], dtype=np.uint64)]).Prepare().Run() == 4
+    assert o.SumGpu(dev, [np.array([(1 << 63) - 1, 1], dtype=np.int64)]).Prepare().Run() == -(1 << 63)
+    assert o.SumGpu(dev, [np.full(1 << 20, -7, dtype=np.int32)]).Prepare().Run() == -7 * (1 << 20)
+    assert o.SumGpu(dev, []).Prepare().Run() == 0
+
+
+# ------------------------------------------------------------------- take
+def test_take_reference_kat(dev, kats):
+    o = _ops()
+    small = np.array(kats["small_column"], dtype=np.uint32)
+    idx = np.array(kats["take_indices"], dtype=np.uint32)
+    res = o.TakeGpu(dev, [small], [idx]).Prepare().Run()
+    assert res[0].tolist() == kats["take_simple_test"]["expected"]
+
+
+@pytest.mark.parametrize("t", list(TYPES))
+def test_take_vs_arrow_golden(dev, golden, t):
+    o = _ops()
+    data = split_batches(golden[f"rand_{t}_values"], golden[f"rand_{t}_sizes"])[-1]
+    idx = golden[f"rand_{t}_take_idx"]
+    res = o.TakeGpu(dev, [data], [idx]).Prepare().Run()
+    np.testing.assert_array_equal(res[0], golden[f"rand_{t}_take_out"])
+
+
+@pytest.mark.parametrize("space", ["host", "device"])
+def test_take_large_test_shape(dev, space):
+    """TakeTest.LargeTest: 128 batches x 64Ki rows, 8Ki indices each."""
+    o = _ops()
+    rng = np.random.default_rng(42)
+    nb = 128
+    data = [rng.integers(0, 1 << 32, size=65536, dtype=np.uint32) for _ in range(nb)]
+    idx = [rng.integers(0, 65536, size=8192, dtype=np.uint32) for _ in range(nb)]
+    idx[5] = idx[5][:1000]  # ragged + partial tile
+    if space == "device":
+        res = o.TakeGpu(dev, [dev.to_device(d) for d in data], [dev.to_device(i) for i in idx]).Prepare().Run()
+        res = [dev.to_host(r) for r in res]
+    else:
+        res = o.TakeGpu(dev, data, idx).Prepare().Run()
+    for b in range(nb):
+        np.testing.assert_array_equal(res[b], oracle.take(data[b], idx[b]))
+
+
+# -------------------------------------------------------------- partition
+def test_partition_reference_kat(dev, kats):
+    o = _ops()
+    p = kats["partition_simple_test"]
+    parts = o.PartitionGpu(dev, [(np.array(p["pk"], np.uint32), np.array(p["x"], np.uint32))], p["nr_partitions"]).Prepare().Run()
+    assert [k.size for k, _ in parts] == p["expected_sizes"]  # PartitionTest.SimpleTest
+    assert sum(int(k.astype(np.uint64).sum()) for k, _ in parts) == p["expected_sum_pk"]
+    assert sum(int(x.astype(np.uint64).sum()) for _, x in parts) == p["expected_sum_x"]
+
+
+@pytest.mark.parametrize("P", [2, 32, 1024, 4096])
+@pytest.mark.parametrize("space", ["host", "device"])
+def test_partition_vs_oracle(dev, P, space):
+    o = _ops()
+    rng = np.random.default_rng(P)
+    sizes = [65536, 1, 0, 40000, 8192, 8191]
+    keys = [rng.integers(0, 1 << 32, size=s, dtype=np.uint32) for s in sizes]
+    pay = [rng.integers(0, 1 << 32, size=s, dtype=np.uint32) for s in sizes]
+    if space == "device":
+        batches = [(dev.to_device(k), dev.to_device(v)) for k, v in zip(keys, pay)]
+    else:
+        batches = list(zip(keys, pay))
+    parts = o.PartitionGpu(dev, batches, P).Prepare().Run()
+    allk, allp = np.concatenate(keys), np.concatenate(pay)
+    bucket = oracle.wang_hash_np(allk) >> np.uint32(32 - int(np.log2(P)))
+    assert sum(k.size for k, _ in parts) == allk.size
+    for p in (0, 1, P // 2, P - 1):
+        k, v = parts[p]
+        assert (oracle.wang_hash_np(k) >> np.uint32(32 - int(np.log2(P))) == p).all()
+        ek, ev = sort_rows(allk[bucket == p], allp[bucket == p])
+        gk, gv = sort_rows(k, v)
+        np.testing.assert_array_equal(gk, ek)
+        np.testing.assert_array_equal(gv, ev)
+    # sizes of every partition == oracle's per-batch histograms summed (join_dpu.cc:54-66)
+    counts = np.zeros(P, dtype=np.int64)
+    for kb in keys:
+        if kb.size:
+            _, _, hist = oracle.partition(kb, P)
+            counts += np.diff(np.concatenate([[0], hist]))
+    assert [k.size for k, _ in parts] == counts.tolist()
+
+
+def test_partition_keys_only_returns_row_ids(dev):
+    o = _ops()
+    rng = np.random.default_rng(3)
+    keys = [rng.integers(0, 1 << 32, size=10000, dtype=np.uint32) for _ in range(3)]
+    parts = o.PartitionGpu(dev, keys, 16, payload_column=None).Prepare().Run()
+    allk = np.concatenate(keys)
+    for k, rid in parts:
+        np.testing.assert_array_equal(allk[rid], k)  # selection_indices_vector semantics
+
+
+# ------------------------------------------------------------------- join
+def _join_sorted(dev, lfk, ly, rpk, rx, device=False, **cfg):
+    o = _ops()
+    dev.join_configure(cfg.get("bits", -1), cfg.get("max_bits", 0))
+    try:
+        if device:
+            lb = [(dev.to_device(a), dev.to_device(b)) for a, b in zip(lfk, ly)]
+            rb = [(dev.to_device(a), dev.to_device(b)) for a, b in zip(rpk, rx)]
+        else:
+            lb, rb = list(zip(lfk, ly)), list(zip(rpk, rx))
+        j = o.JoinGpu(dev, lb, rb).Prepare()
+        out = j.Run()
+        if device:
+            out = {k: dev.to_host(v) for k, v in out.items()}
+    finally:
+        dev.join_configure(-1, 0)
+    return sort_rows(out["fk"], out["y"], out["x"]), j.stats
+
+
+def test_join_simple_test_kat(dev, kats):
+    """JoinTest.SimpleTest: keys shuffled across batches; compare after sort by (v_l, fk)."""
+    j = kats["join_simple_test"]
+    a = lambda k: [np.array(b, dtype=np.uint32) for b in j[k]]
+    (fk, y, x), _ = _join_sorted(dev, a("left_fk"), a("left_v_l"), a("right_pk"), a("right_v_r"))
+    y2, fk2, x2 = sort_rows(y, fk, x)
+    np.testing.assert_array_equal(fk2, np.array(j["expected_sorted_fk"], dtype=np.uint32))
+    np.testing.assert_array_equal(y2, np.array(j["expected_sorted_v_l"], dtype=np.uint32))
+    np.testing.assert_array_equal(x2, np.array(j["expected_sorted_v_r"], dtype=np.uint32))
+
+
+@pytest.mark.parametrize("case", ["a", "b"])
+@pytest.mark.parametrize("cfg", [dict(), dict(bits=1), dict(bits=6, max_bits=2), dict(bits=12, max_bits=4), dict(bits=11), dict(bits=16, max_bits=8)])
+@pytest.mark.parametrize("device", [False, True])
+def test_join_vs_arrow_golden(dev, golden, case, cfg, device):
+    """Arrow (Acero hash join) golden rows; every radix configuration -- 1, 2, 3 and 4
+    passes -- must give the same table."""
+    lf = split_batches(golden[f"join_{case}_fk"], golden[f"join_{case}_left_rows"])
+    ly = split_batches(golden[f"join_{case}_y"], golden[f"join_{case}_left_rows"])
+    rp = split_batches(golden[f"join_{case}_pk"], golden[f"join_{case}_right_rows"])
+    rx = split_batches(golden[f"join_{case}_x"], golden[f"join_{case}_right_rows"])
+    (fk, y, x), stats = _join_sorted(dev, lf, ly, rp, rx, device=device, **cfg)
+    np.testing.assert_array_equal(fk, golden[f"join_{case}_out_fk"])
+    np.testing.assert_array_equal(y, golden[f"join_{case}_out_y"])
+    np.testing.assert_array_equal(x, golden[f"join_{case}_out_x"])
+    assert stats["missing_keys"] == 0 and stats["duplicate_keys"] == 0
+    if "bits" in cfg:
+        assert sum(stats["radix_bits"]) == cfg["bits"]
+
+
+def test_join_large_test_shape_vs_oracle(dev):
+    """JoinTest.LargeTest: 128 x 64Ki rows per side, generator data; all columns equal after
+    sort by (fk, y); row count == left rows."""
+    from dpu_olap_amd import datagen as dg
+    nb, L, R = 128, 65536, 65536
+    pk = [dg.index_u32(R, b * R) for b in range(nb)]
+    x = [dg.uniform_u32(R, dg.SEED, dg.STREAM_X, b * R) for b in range(nb)]
+    fk = [dg.fk_u32(L, dg.SEED, dg.STREAM_FK, b * L, L, R) for b in range(nb)]
+    y = [dg.uniform_u32(L, dg.SEED, dg.STREAM_Y, b * L) for b in range(nb)]
+    (gfk, gy, gx), stats = _join_sorted(dev, fk, y, pk, x, device=True)
+    assert gfk.size == nb * L
+    ofk, oy, ox = oracle.join(fk, y, pk, x, nr_partitions=128)
+    ofk, oy, ox = sort_rows(ofk, oy, ox)
+    np.testing.assert_array_equal(gfk, ofk)
+    np.testing.assert_array_equal(gy, oy)
+    np.testing.assert_array_equal(gx, ox)
+    assert stats["passes"] >= 1 and stats["max_build_rows"] <= 6144
+
+
+def test_join_partition_major_output_order(dev):
+    o = _ops()
+    rng = np.random.default_rng(5)
+    pk = rng.permutation(1 << 16).astype(np.uint32)
+    x = rng.integers(0, 1 << 32, size=pk.size, dtype=np.uint32)
+    fk = pk[rng.integers(0, pk.size, size=100000)]
+    y = np.arange(fk.size, dtype=np.uint32)
+    j = o.JoinGpu(dev, [(fk, y)], [(pk, x)]).Prepare()
+    out = j.Run()
+    bits = sum(j.stats["radix_bits"])
+    part = oracle.wang_hash_np(out["fk"]) >> np.uint32(32 - bits)
+    assert (np.diff(part.astype(np.int64)) >= 0).all()  # join_dpu.cc:371-399
+    lut = np.zeros(1 << 16, dtype=np.uint32)
+    lut[pk] = x
+    np.testing.assert_array_equal(out["x"], lut[out["fk"]])
+    np.testing.assert_array_equal(out["fk"], fk[out["y"]])
+
+
+def test_join_missing_key_is_an_error(dev):
+    o = _ops()
+    pk = np.arange(1000, dtype=np.uint32)
+    x = pk + np.uint32(5)
+    fk = np.array([1, 2, 5000], dtype=np.uint32)
+    with pytest.raises(o.OlapError) as e:
+        o.JoinGpu(dev, [(fk, fk)], [(pk, x)]).Prepare().Run()
+    assert e.value.code == -4  # OLAP_ERR_NO_MATCH (reference asserts, hash_probe.c:32-33)
+    with pytest.raises(o.OlapError):
+        o.JoinGpu(dev, [(fk, fk)], []).Prepare().Run()
+
+
+def test_join_duplicate_build_keys_overwrite(dev):
+    o = _ops()
+    pk = np.array([7, 7, 9], dtype=np.uint32)
+    x = np.array([1, 1, 3], dtype=np.uint32)
+    fk = np.array([9, 7], dtype=np.uint32)
+    j = o.JoinGpu(dev, [(fk, fk)], [(pk, x)]).Prepare()
+    out = j.Run()
+    assert sorted(zip(out["fk"].tolist(), out["x"].tolist())) == [(7, 1), (9, 3)]  # hashtable.c:133
+    assert j.stats["duplicate_keys"] == 1
+
+
+def test_join_empty_left_and_skew(dev):
+    o = _ops()
+    pk = np.arange(100, dtype=np.uint32)
+    assert o.JoinGpu(dev, [], [(pk, pk)]).Prepare().Run()["fk"].size == 0
+    # all probes hit the same key: one huge probe partition
+    fk = np.full(300000, 42, dtype=np.uint32)
+    out = o.JoinGpu(dev, [(fk, np.arange(fk.size, dtype=np.uint32))], [(pk, pk + np.uint32(1))]).Prepare().Run()
+    assert out["fk"].size == fk.size and (out["x"] == 43).all()
+    assert np.array_equal(np.sort(out["y"]), np.arange(fk.size, dtype=np.uint32))
+
+
+# -------------------------------------------------- generator + full-size style properties
+def test_device_generator_matches_host_mirror(dev):
+    from dpu_olap_amd import datagen as dg
+    n = 100003
+    d = dev.empty(n, "uint32")
+    dev.gen_uniform_u32(d.ptr, n, 42, dg.STREAM_V, 12345)
+    np.testing.assert_array_equal(dev.to_host(d), dg.uniform_u32(n, 42, dg.STREAM_V, 12345))
+    dev.gen_index_u32(d.ptr, n, 77)
+    np.testing.assert_array_equal(dev.to_host(d), dg.index_u32(n, 77))
+    dev.gen_fk_u32(d.ptr, n, 42, dg.STREAM_FK, 1000, 3000, 2048)
+    np.testing.assert_array_equal(dev.to_host(d), dg.fk_u32(n, 42, dg.STREAM_FK, 1000, 3000, 2048))
+    rows = dev.to_device(np.arange(5, 5 + n, dtype=np.uint32))
+    dev.gen_uniform_u32_at(d.ptr, rows.ptr, n, 42, dg.STREAM_X)
+    np.testing.assert_array_equal(dev.to_host(d), dg.uniform_u32(n, 42, dg.STREAM_X, 5))
+    d64 = dev.empty(n, "uint64")
+    dev.gen_uniform_u64(d64.ptr, n, 42, 9, 3)
+    h64 = dg.uniform_u64(n, 42, 9, 3)
+    np.testing.assert_array_equal(dev.to_host(d64), h64)
+    assert dev.checksum(d64.ptr, n, 8) == dg.checksum(h64)
+    h = dev.to_host(d)
+    assert dev.checksum(d.ptr, n, 4) == dg.checksum(h)
+    assert dev.checksum_rows3_u32(d.ptr, rows.ptr, d.ptr, n) == dg.checksum_rows3(h, np.arange(5, 5 + n, dtype=np.uint32), h)
+
+
+@pytest.mark.parametrize("sf", [8, 64])
+def test_join_generator_scale_digest(dev, sf):
+    """Size-independent property at benchmark shape (SF batches x 2Mi rows per side,
+    join_benchmark.cc:170-171): pk is the global row index, so the joined x of a row must
+    be gen32(STREAM_X, fk); the digest of the output rows {fk, y, x} must equal the digest
+    of {fk_in, y_in, gen_at(fk_in)} computed from the inputs, row order ignored."""
+    o = _ops()
+    from dpu_olap_amd import datagen as dg
+    rows = 2 << 20
+    n = sf * rows
+    cols = {k: dev.empty(n, "uint32") for k in ("fk", "y", "pk", "x", "exp")}
+    dev.gen_fk_u32(cols["fk"].ptr, n, dg.SEED, dg.STREAM_FK, 0, rows, rows)
+    dev.gen_uniform_u32(cols["y"].ptr, n, dg.SEED, dg.STREAM_Y, 0)
+    dev.gen_index_u32(cols["pk"].ptr, n, 0)
+    dev.gen_uniform_u32(cols["x"].ptr, n, dg.SEED, dg.STREAM_X, 0)
+    dev.gen_uniform_u32_at(cols["exp"].ptr, cols["fk"].ptr, n, dg.SEED, dg.STREAM_X)
+    expect = dev.checksum_rows3_u32(cols["fk"].ptr, cols["y"].ptr, cols["exp"].ptr, n)
+    batch = lambda c, b: o.DeviceArray(cols[c].ptr + 4 * b * rows, rows, "uint32")
+    j = o.JoinGpu(dev, [(batch("fk", b), batch("y", b)) for b in range(sf)],
+                  [(batch("pk", b), batch("x", b)) for b in range(sf)]).Prepare()
+    out = j.Run()
+    assert out["fk"].rows == n
+    got = dev.checksum_rows3_u32(out["fk"].ptr, out["y"].ptr, out["x"].ptr, n)
+    assert got == expect
+    assert j.stats["missing_keys"] == 0 and j.stats["max_build_rows"] <= j.stats["table_slots"] * 3 // 4
+    if sf == 8:  # and the oracle agrees on this size (a few seconds of CPU)
+        h = {k: dev.to_host(cols[k]) for k in ("fk", "y", "pk", "x")}
+        sp = lambda a: [a[b * rows:(b + 1) * rows] for b in range(sf)]
+        ofk, oy, ox = oracle.join(sp(h["fk"]), sp(h["y"]), sp(h["pk"]), sp(h["x"]), nr_partitions=64)
+        assert dg.checksum_rows3(ofk, oy, ox) == got
+    for c in list(cols.values()) + list(out.values()):
+        dev.release(o.DeviceArray(c.ptr, 0))
