@@ -1,0 +1,251 @@
+#!/usr/bin/env python3
+"""bench.py -- BM_Join-equivalent (radix-partitioned PK-FK hash join, u32 columns) on
+N MI355X GPUs, one process per GPU.
+
+  python bench.py --gpus 1 --steps K --warmup W                      (single GPU)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W      (N GPUs, RCCL)
+
+Workload (BASELINE.json configs[3], reference host/join/join_benchmark.cc:145-171):
+BM_Join {Batches=SF, L-Batch-Size=2Mi, R-Batch-Size=2Mi}, SF=2048 -> 2^32 rows per
+side; right {pk = global row index, x uniform u32}, left {fk uniform in the matching
+right batch's key range, y uniform u32}; synthetic, generated in HBM by the counter-
+based generator (dpu_olap_amd/csrc/gen.hip).  One "step" = one full join (partition of
+both tables + build + probe + materialise {fk, y, x}) of the resident inputs, Prepare()
+inside the timed region like the reference.  value = (left rows + right rows) / time.
+At N > 1 the SAME total problem (SF=2048) is split over the ranks (strong scaling:
+SF=16384 of BASELINE configs[4] needs 2^35 unique keys, which uint32 cannot hold --
+SURVEY.md gotcha 5) and the ranks exchange tuples once (all-to-all over xGMI).
+
+Prints ONE JSON line on rank 0.  The oracle is used only for the cpu_baseline leg.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+BATCH_ROWS = 2 << 20           # join_benchmark.cc:170-171
+HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+JOIN_ALG_BYTES_PER_PAIR = 28   # read 2 cols x 2 tables (16 B) + write 3 cols (12 B)
+SCATTER_ALG_BYTES_PER_TUPLE = 16  # dominant kernel: one (key,payload) tuple read + written once
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--sf", type=int, default=0, help="scale factor (default 2048, or the largest that fits)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sf", type=int, default=0, help="scale factor of the bounded CPU sample (default: auto)")
+    return ap.parse_args()
+
+
+def cpu_baseline(cores_hint: int, cpu_sf: int):
+    """The oracle (CPU restatement of the reference's partition/build/probe/take pipeline,
+    oracle/olap_oracle.c, OpenMP over batches and partitions) timed on this box's host
+    cores on a bounded sample of the same workload shape, plus Arrow's Acero hash join
+    (the library behind the reference's JoinNative) on the same sample."""
+    import numpy as np
+    import oracle
+    from dpu_olap_amd import datagen as dg
+
+    threads = oracle.max_threads()
+    sf = cpu_sf or max(2, min(32, 1 << (max(threads, 1).bit_length())))
+    rows = BATCH_ROWS
+    sp = lambda fn: [fn(b) for b in range(sf)]
+    pk = sp(lambda b: dg.index_u32(rows, b * rows))
+    x = sp(lambda b: dg.uniform_u32(rows, dg.SEED, dg.STREAM_X, b * rows))
+    fk = sp(lambda b: dg.fk_u32(rows, dg.SEED, dg.STREAM_FK, b * rows, rows, rows))
+    y = sp(lambda b: dg.uniform_u32(rows, dg.SEED, dg.STREAM_Y, b * rows))
+    n = sf * rows
+    P = max(2, 1 << (max(sf, 2) - 1).bit_length())  # reference: #partitions == #batches (join_dpu.cc:168)
+    t0 = time.perf_counter()
+    ofk, oy, ox = oracle.join(fk, y, pk, x, nr_partitions=P, threads=threads)
+    dt = time.perf_counter() - t0
+    assert ofk.size == n
+    out = {
+        "value": round(2 * n / dt / 1e6, 2), "unit": "Mrows/s", "cores": threads, "kind": "port",
+        "sample": f"BM_Join shape at SF={sf} ({sf} batches x 2Mi rows per side, {P} partitions), oracle/olap_oracle.c, one run, {dt:.2f} s",
+    }
+    arrow = None
+    try:
+        import pyarrow as pa
+        tl = pa.table({"fk": pa.chunked_array([pa.array(a) for a in fk]), "y": pa.chunked_array([pa.array(a) for a in y])})
+        tr = pa.table({"pk": pa.chunked_array([pa.array(a) for a in pk]), "x": pa.chunked_array([pa.array(a) for a in x])})
+        t0 = time.perf_counter()
+        res = tl.join(tr, keys="fk", right_keys="pk", join_type="inner", use_threads=True)
+        da = time.perf_counter() - t0
+        assert res.num_rows == n
+        arrow = {"value": round(2 * n / da / 1e6, 2), "unit": "Mrows/s", "cores": pa.cpu_count(),
+                 "kind": f"Arrow {pa.__version__} Acero hash join (the reference's JoinNative plan, join_native.cc:31-49)",
+                 "sample": f"same SF={sf} sample, {da:.2f} s"}
+    except Exception as e:  # pragma: no cover
+        arrow = {"error": repr(e)}
+    return out, arrow
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from dpu_olap_amd import capi
+    from dpu_olap_amd import datagen as dg
+    from dpu_olap_amd.dist_join import GpuLocalOps, distributed_join
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the hot path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+    ctx = capi.Context(local_rank)
+    info = ctx.device_info()
+    ops = GpuLocalOps(ctx, device)
+
+    # ---- workload size
+    free = info["free_mem"]
+    sf = args.sf or 2048
+    def need_bytes(sf_total):  # per rank: inputs + outputs + arena (3 tuple buffers) (+ exchange buffers at N > 1)
+        n = sf_total * BATCH_ROWS // world
+        single = 16 * n + 12 * n + 24 * n
+        extra = (16 * n + 16 * n) * 1.15 if world > 1 else 0
+        return (single + extra) * 1.03 + (2 << 30)
+    while not args.sf and sf > world and need_bytes(sf) > free:
+        sf //= 2
+    if sf % world:
+        raise SystemExit(f"SF={sf} must be a multiple of the number of GPUs ({world})")
+    my_batches = sf // world
+    n_local = my_batches * BATCH_ROWS
+    n_total = sf * BATCH_ROWS
+    first_batch = rank * my_batches            # contiguous slice of the batches per rank
+    first_row = first_batch * BATCH_ROWS
+
+    def col():
+        return torch.empty(n_local, dtype=torch.int32, device=device)
+    fk, y, pk, x = col(), col(), col(), col()
+    ctx.gen_fk_u32(fk.data_ptr(), n_local, dg.SEED, dg.STREAM_FK, first_row, BATCH_ROWS, BATCH_ROWS)
+    ctx.gen_uniform_u32(y.data_ptr(), n_local, dg.SEED, dg.STREAM_Y, first_row)
+    ctx.gen_index_u32(pk.data_ptr(), n_local, first_row & 0xFFFFFFFF)
+    ctx.gen_uniform_u32(x.data_ptr(), n_local, dg.SEED, dg.STREAM_X, first_row)
+    batches = lambda k, p: [(k[b * BATCH_ROWS:(b + 1) * BATCH_ROWS], p[b * BATCH_ROWS:(b + 1) * BATCH_ROWS]) for b in range(my_batches)]
+    left, right = batches(fk, y), batches(pk, x)
+
+    # expected digest of the join result, from the inputs alone: pk is the global row
+    # index, so x(fk) = gen32(STREAM_X, fk).  Order independent; summed over ranks.
+    exp = col()
+    ctx.gen_uniform_u32_at(exp.data_ptr(), fk.data_ptr(), n_local, dg.SEED, dg.STREAM_X)
+    exp_sum, _ = ctx.checksum_rows3_u32(fk.data_ptr(), y.data_ptr(), exp.data_ptr(), n_local)
+    del exp
+    torch.cuda.empty_cache()
+
+    def sync_all():
+        torch.cuda.synchronize(device)
+        ctx.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    def step():
+        ctx.set_profiling(True)    # Prepare(): per-phase HIP-event timers (inside the timed region, like the reference)
+        return distributed_join(ops, left, right)
+
+    result = None
+    for _ in range(args.warmup):
+        result = None
+        result = step()
+    sync_all()
+    ctx.reset_timers()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        result = None          # drop the previous step's output before allocating the next
+        result = step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    timers = ctx.timers()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- verification (outside the timed region)
+    ofk, oy, ox, jinfo = result
+    got_sum, _ = ctx.checksum_rows3_u32(ofk.data_ptr(), oy.data_ptr(), ox.data_ptr(), ofk.numel())
+    rows_out = ofk.numel()
+    if world > 1:
+        v = torch.tensor([got_sum & 0x7FFFFFFF, got_sum >> 31, exp_sum & 0x7FFFFFFF, exp_sum >> 31, rows_out], dtype=torch.int64, device=device)
+        parts = [torch.empty_like(v) for _ in range(world)]
+        dist.all_gather(parts, v)
+        M = (1 << 64) - 1
+        got_sum = sum(int(p[0]) + (int(p[1]) << 31) for p in parts) & M
+        exp_sum = sum(int(p[2]) + (int(p[3]) << 31) for p in parts) & M
+        rows_out = sum(int(p[4]) for p in parts)
+    verified = bool(got_sum == exp_sum and rows_out == n_total)
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = 2 * n_total / (dt / args.steps) / 1e6
+        # dominant kernel from the live HIP-event timers of the timed region
+        kern = {k: v for k, v in timers.items() if k.startswith(("partition-", "join-"))}
+        dom = max(kern, key=lambda k: kern[k]["ms"]) if kern else None
+        roofline = None
+        if dom:
+            avg_ms = kern[dom]["ms"] / max(kern[dom]["launches"], 1)
+            # a phase scope brackets exactly one kernel launch for hist / scatter / join-probe
+            per_launch_units = {"partition-scatter": n_local, "partition-hist": n_local, "join-probe": n_local}
+            alg_per_unit = {"partition-scatter": SCATTER_ALG_BYTES_PER_TUPLE, "partition-hist": 6, "join-probe": JOIN_ALG_BYTES_PER_PAIR}
+            alg = alg_per_unit.get(dom, 16) * per_launch_units.get(dom, n_local)
+            ach = alg / (avg_ms * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
+                        "avg_launch_ms": round(avg_ms, 4), "launches": kern[dom]["launches"],
+                        "algorithmic_bytes_per_launch": alg}
+        whole = JOIN_ALG_BYTES_PER_PAIR * n_total / (dt / args.steps) / 1e9
+        line = {
+            "metric": "Mrows/s for BM_Join (build+probe) at SF=2048",
+            "value": round(value, 1), "unit": "Mrows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u32", "data": "synthetic",
+            "config": {"workload": f"BM_Join u32 PK-FK SF={sf}: {sf} batches x 2Mi rows per side ({n_total} rows/side), "
+                                   f"{world} x MI355X" + (", hash-owner split + all-to-all" if world > 1 else ""),
+                       "sf": sf, "rows_per_side": n_total, "batch_rows": BATCH_ROWS, "radix": jinfo["stats"],
+                       "device": info["name"].strip()},
+            "verified": verified, "rows_out": rows_out,
+            "roofline": roofline,
+            "roofline_whole_join": {"bound": "hbm", "achieved": round(whole, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                    "frac": round(whole / HBM_PEAK_GBPS, 4),
+                                    "note": "28 B per row-pair (SURVEY 8d) x rows/side / wall time per step, all GPUs"},
+            "phase_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in timers.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            del left, right, result, ofk, oy, ox
+            cb, arrow = cpu_baseline(os.cpu_count() or 1, args.cpu_sf)
+            line["cpu_baseline"] = cb
+            line["cpu_baseline_arrow"] = arrow
+        print(json.dumps(line), flush=True)
+        if not verified:
+            print("VERIFICATION FAILED: output digest does not match the inputs", file=sys.stderr)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+    return 0 if verified else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())

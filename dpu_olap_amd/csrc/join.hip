@@ -474,7 +474,8 @@ static uint64_t side_scratch_bytes(const olap_ctx* ctx, uint64_t rows, const Pas
 
 // Runs all passes of one side.  `cs` views the key/payload columns with unit_rows = kPTile.
 static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, const PassPlan& plan,
-                          uint2* tmp0, uint2* tmp1, uint2* final_tuples, uint64_t** final_off) {
+                          uint32_t skip_bits, uint2* tmp0, uint2* tmp1, uint2* final_tuples,
+                          uint64_t** final_off) {
   const uint64_t rows = cs.view.total_rows;
   PassSrc src{};
   src.v = cs.view;
@@ -483,7 +484,7 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
   uint64_t n_seg = 1;
   const uint64_t* seg_in = nullptr;
   const uint2* in_tuples = nullptr;
-  uint32_t consumed = 0;
+  uint32_t consumed = skip_bits;
   OLAP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_scatter<SRC_COLS>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, kScatterLds));
   OLAP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_scatter<SRC_TUPLES>),
@@ -564,6 +565,8 @@ static int join_once(olap_ctx* ctx, const uint32_t* const* lfk, const uint32_t* 
                      uint64_t NL, uint64_t NR, uint32_t total_bits, olap_join_stats* st, unsigned long long counters[4]) {
   PassPlan plan;
   OLAP_TRY(make_plan(ctx, total_bits, &plan));
+  if (plan.total_bits + (uint32_t)ctx->hash_skip_bits > 32)
+    return ctx->fail(OLAP_ERR_INVALID, "radix bits (%u) + skipped hash bits (%d) exceed 32", plan.total_bits, ctx->hash_skip_bits);
   const uint32_t P = 1u << plan.total_bits;
   const uint32_t eb[2] = {4, 4};
   const void* const* lcols[2] = {(const void* const*)lfk, (const void* const*)ly};
@@ -595,8 +598,8 @@ static int join_once(olap_ctx* ctx, const uint32_t* const* lfk, const uint32_t* 
     return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (join buffers)");
   OLAP_HIP(ctx, hipMemsetAsync(d_cnt, 0, 32, ctx->stream));
   uint64_t *l_off = nullptr, *r_off = nullptr;
-  OLAP_TRY(partition_side(ctx, lcs, true, plan, tmp0, tmp1, Lt, &l_off));
-  OLAP_TRY(partition_side(ctx, rcs, true, plan, tmp0, tmp1, Rt, &r_off));
+  OLAP_TRY(partition_side(ctx, lcs, true, plan, (uint32_t)ctx->hash_skip_bits, tmp0, tmp1, Lt, &l_off));
+  OLAP_TRY(partition_side(ctx, rcs, true, plan, (uint32_t)ctx->hash_skip_bits, tmp0, tmp1, Rt, &r_off));
   {
     PhaseScope ps(ctx, PH_JOIN_PROBE);
     uint64_t grid = (uint64_t)ctx->compute_units * 8;
@@ -633,6 +636,13 @@ static int join_once(olap_ctx* ctx, const uint32_t* const* lfk, const uint32_t* 
 using namespace olap;
 
 extern "C" {
+
+int olap_join_set_hash_skip_bits(olap_ctx* ctx, int bits) {
+  if (!ctx) return OLAP_ERR_INVALID;
+  if (bits < 0 || bits > 16) return ctx->fail(OLAP_ERR_INVALID, "hash skip bits must be in [0, 16]");
+  ctx->hash_skip_bits = bits;
+  return OLAP_OK;
+}
 
 int olap_join_configure(olap_ctx* ctx, int radix_bits_total, int max_bits_per_pass) {
   if (!ctx) return OLAP_ERR_INVALID;
@@ -682,7 +692,7 @@ int olap_join_u32(olap_ctx* ctx, const uint32_t* const* left_fk_ptrs, const uint
                        counters));
     if (counters[2] == 0) break;
     bits += 2;  // a build partition overflowed the LDS table: split finer and retry
-    if (bits > 28) break;
+    if (bits + (uint32_t)ctx->hash_skip_bits > 28) break;
   }
   if (counters[2])
     return ctx->fail(OLAP_ERR_OVERFLOW, "%llu partition(s) exceed the LDS hash table (%u rows); largest build partition %llu rows",
@@ -734,7 +744,7 @@ int olap_partition_u32(olap_ctx* ctx, const uint32_t* const* key_ptrs, const uin
   if ((plan.passes >= 2 && !tmp0) || (plan.passes >= 3 && !tmp1) || !fin || (N && (!d_k || !d_p)))
     return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (partition buffers)");
   uint64_t* off = nullptr;
-  OLAP_TRY(partition_side(ctx, cs, payload_ptrs != nullptr, plan, tmp0, tmp1, fin, &off));
+  OLAP_TRY(partition_side(ctx, cs, payload_ptrs != nullptr, plan, 0u, tmp0, tmp1, fin, &off));
   if (N) {
     PhaseScope ps(ctx, PH_PART_SCATTER);
     uint64_t grid = (N + 255) / 256;

@@ -1,0 +1,145 @@
+"""Multi-GPU PK-FK join: one process per GPU (torch.distributed; backend "nccl" is RCCL
+on ROCm), hash-owner partitioning and ONE all-to-all exchange over xGMI.
+
+This is the only step of the path that needs communication, and it sits exactly
+where the reference shuffles partitions through host DRAM
+(Partitioner::GetOffsets / LoadPartitions, host/partition/partitioner.cc:280-375;
+host->DPU reload, host/join/join_dpu.cc:269,293):
+
+  1. every rank holds a slice of the batches of both tables;
+  2. each rank groups its tuples by owner = top log2(G) bits of wang_hash(key)
+     (the reference's BUCKET_OF with nr_partitions = G, partition.c:45-46) --
+     olap_partition_u32, so each destination's tuples are one contiguous region;
+  3. counts, then keys and payloads, are exchanged with all_to_all_single
+     (per-peer message ~ 1/G of the local rows; xGMI is point to point, each
+     message rides its own link);
+  4. each rank runs the single-GPU join on what it received, telling it that the
+     top log2(G) hash bits are already fixed (olap_join_set_hash_skip_bits).
+The result stays sharded by owner (the reference's output is a list of per-
+partition batches too, join_dpu.cc:371-399).
+
+`ops` abstracts the local operators so the host logic can be exercised on CPU with
+gloo in tests (tests provide an oracle-backed ops object); the product backend is
+GpuLocalOps (C ABI on device pointers of torch CUDA tensors)."""
+from __future__ import annotations
+
+from typing import Sequence
+
+import torch
+import torch.distributed as dist
+
+from . import capi
+
+
+def _i32(t: torch.Tensor) -> torch.Tensor:
+    return t if t.dtype == torch.int32 else t.view(torch.int32)
+
+
+class GpuLocalOps:
+    """Local partition / join through libolap_gpu.so on torch CUDA tensors (int32 tensors
+    carry the uint32 bit patterns; torch is only the allocator and the RCCL front end)."""
+
+    def __init__(self, ctx: capi.Context, device: torch.device):
+        self.ctx = ctx
+        self.device = device
+
+    def empty(self, n: int) -> torch.Tensor:
+        return torch.empty(max(n, 1), dtype=torch.int32, device=self.device)[:n]
+
+    def partition(self, keys: Sequence[torch.Tensor], payload: Sequence[torch.Tensor], nr_partitions: int):
+        rows = [int(k.numel()) for k in keys]
+        n = sum(rows)
+        ok, op = self.empty(n), self.empty(n)
+        torch.cuda.synchronize(self.device)
+        offs = self.ctx.partition_u32([k.data_ptr() for k in keys], [p.data_ptr() for p in payload], rows,
+                                      capi.MEM_DEVICE, nr_partitions, ok.data_ptr(), op.data_ptr(), n, capi.MEM_DEVICE)
+        return ok, op, offs
+
+    def join(self, lfk, ly, rpk, rx, skip_bits: int = 0):
+        lrows = [int(t.numel()) for t in lfk]
+        rrows = [int(t.numel()) for t in rpk]
+        n = sum(lrows)
+        out = [self.empty(n) for _ in range(3)]
+        torch.cuda.synchronize(self.device)
+        self.ctx.join_set_hash_skip_bits(skip_bits)
+        try:
+            got, stats = self.ctx.join_u32([t.data_ptr() for t in lfk], [t.data_ptr() for t in ly], lrows,
+                                           [t.data_ptr() for t in rpk], [t.data_ptr() for t in rx], rrows,
+                                           capi.MEM_DEVICE, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(),
+                                           n, capi.MEM_DEVICE)
+        finally:
+            self.ctx.join_set_hash_skip_bits(0)
+        return out[0][:got], out[1][:got], out[2][:got], stats
+
+
+def _exchange(send: torch.Tensor, in_splits, out_splits, empty, group) -> torch.Tensor:
+    """Personalised all-to-all of a 1-D tensor.  RCCL/NCCL: all_to_all_single; backends
+    without it (gloo on some builds): pairwise isend/irecv."""
+    recv = empty(int(sum(out_splits)))
+    try:
+        dist.all_to_all_single(recv, send, output_split_sizes=list(out_splits), input_split_sizes=list(in_splits), group=group)
+        return recv
+    except (RuntimeError, NotImplementedError):
+        pass
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    so = [0]
+    for s in in_splits:
+        so.append(so[-1] + s)
+    ro = [0]
+    for s in out_splits:
+        ro.append(ro[-1] + s)
+    recv[ro[rank]:ro[rank + 1]].copy_(send[so[rank]:so[rank + 1]])
+    reqs = []
+    for peer in range(world):
+        if peer == rank:
+            continue
+        gp = dist.get_global_rank(group, peer) if group is not None else peer
+        if in_splits[peer]:
+            reqs.append(dist.isend(send[so[peer]:so[peer + 1]].contiguous(), gp, group=group))
+        if out_splits[peer]:
+            reqs.append(dist.irecv(recv[ro[peer]:ro[peer + 1]], gp, group=group))
+    for r in reqs:
+        r.wait()
+    return recv
+
+
+def distributed_join(ops, left_batches: Sequence, right_batches: Sequence, group=None, timers: dict | None = None):
+    """left_batches / right_batches: this rank's batches as (key, payload) tensor pairs.
+    Returns (fk, y, x, info): this rank's shard of the join result (rows whose key it owns)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    lfk, ly = [b[0] for b in left_batches], [b[1] for b in left_batches]
+    rpk, rx = [b[0] for b in right_batches], [b[1] for b in right_batches]
+    if world == 1:
+        fk, y, x, stats = ops.join(lfk, ly, rpk, rx, 0)
+        return fk, y, x, {"world": 1, "stats": stats, "sent_rows": 0}
+    if world & (world - 1):
+        raise ValueError("the owner split uses the top log2(G) hash bits: world size must be a power of two")
+    g = world.bit_length() - 1
+    # (2) group by owner
+    lk, lp, loff = ops.partition(lfk, ly, world)
+    rk, rp, roff = ops.partition(rpk, rx, world)
+    l_in = [loff[p + 1] - loff[p] for p in range(world)]
+    r_in = [roff[p + 1] - roff[p] for p in range(world)]
+    # (3a) counts
+    dev = lk.device
+    cnt_in = torch.tensor(l_in + r_in, dtype=torch.int64, device=dev).view(2, world).t().contiguous().view(-1)
+    cnt_out = torch.empty_like(cnt_in)
+    try:
+        dist.all_to_all_single(cnt_out, cnt_in, group=group)
+    except (RuntimeError, NotImplementedError):
+        gathered = [torch.empty_like(cnt_in) for _ in range(world)]
+        dist.all_gather(gathered, cnt_in, group=group)
+        rank = dist.get_rank(group)
+        cnt_out = torch.stack([gt.view(world, 2)[rank] for gt in gathered]).view(-1)
+    co = cnt_out.view(world, 2).cpu()
+    l_out, r_out = [int(v) for v in co[:, 0]], [int(v) for v in co[:, 1]]
+    # (3b) payload exchange: four columns
+    RLk = _exchange(_i32(lk), l_in, l_out, ops.empty, group)
+    RLp = _exchange(_i32(lp), l_in, l_out, ops.empty, group)
+    RRk = _exchange(_i32(rk), r_in, r_out, ops.empty, group)
+    RRp = _exchange(_i32(rp), r_in, r_out, ops.empty, group)
+    # (4) local join below the owner bits
+    fk, y, x, stats = ops.join([RLk], [RLp], [RRk], [RRp], g)
+    rank = dist.get_rank(group)
+    sent = sum(l_in) + sum(r_in) - l_in[rank] - r_in[rank]
+    return fk, y, x, {"world": world, "stats": stats, "sent_rows": sent, "recv_left": sum(l_out), "recv_right": sum(r_out)}
