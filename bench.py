@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--sf", type=int, default=0, help="scale factor (default 2048, or the largest that fits)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--radix-bits", type=int, default=-1, help="tuning: total radix bits (default auto)")
+    ap.add_argument("--max-bits-per-pass", type=int, default=0, help="tuning: fan-out cap per pass (default 10)")
+    ap.add_argument("--scatter-variant", type=int, default=0, help="tuning: 0 write-combining, 1 tile-staged")
     ap.add_argument("--cpu-sf", type=int, default=0, help="scale factor of the bounded CPU sample (default: auto)")
     return ap.parse_args()
 
@@ -117,6 +120,8 @@ def main():
     ctx = capi.Context(local_rank)
     info = ctx.device_info()
     ops = GpuLocalOps(ctx, device)
+    ctx.join_configure(args.radix_bits, args.max_bits_per_pass)
+    ctx.set_tuning("scatter_variant", args.scatter_variant)
 
     # ---- workload size
     free = info["free_mem"]

@@ -28,7 +28,7 @@ EXPORTS = [
     "olap_set_stream", "olap_get_stream", "olap_synchronize", "olap_reserve_workspace",
     "olap_workspace_bytes", "olap_malloc", "olap_free", "olap_memcpy_h2d", "olap_memcpy_d2h",
     "olap_memset", "olap_set_profiling", "olap_reset_timers", "olap_get_timers", "olap_filter_lt",
-    "olap_sum", "olap_take", "olap_partition_u32", "olap_join_u32", "olap_join_configure", "olap_join_set_hash_skip_bits",
+    "olap_sum", "olap_take", "olap_partition_u32", "olap_join_u32", "olap_join_configure", "olap_join_set_hash_skip_bits", "olap_set_tuning",
     "olap_gen_uniform_u32", "olap_gen_uniform_u64", "olap_gen_index_u32", "olap_gen_fk_u32",
     "olap_gen_uniform_u32_at", "olap_checksum", "olap_checksum_rows3_u32",
 ]
@@ -112,6 +112,7 @@ def load_library(path: str | None = None) -> C.CDLL:
                               C.POINTER(JoinStats)]),
         "olap_join_configure": (i, [vp, i, i]),
         "olap_join_set_hash_skip_bits": (i, [vp, i]),
+        "olap_set_tuning": (i, [vp, C.c_char_p, i]),
         "olap_gen_uniform_u32": (i, [vp, vp, u64, u64, u32, u64]),
         "olap_gen_uniform_u64": (i, [vp, vp, u64, u64, u32, u64]),
         "olap_gen_index_u32": (i, [vp, vp, u64, u32]),
@@ -266,6 +267,9 @@ class Context:
 
     def join_configure(self, radix_bits_total: int = -1, max_bits_per_pass: int = 0):
         self._check(self.lib.olap_join_configure(self.h, radix_bits_total, max_bits_per_pass))
+
+    def set_tuning(self, key: str, value: int):
+        self._check(self.lib.olap_set_tuning(self.h, key.encode(), value))
 
     def join_set_hash_skip_bits(self, bits: int):
         self._check(self.lib.olap_join_set_hash_skip_bits(self.h, bits))

@@ -73,6 +73,8 @@ struct olap_ctx {
   // join tuning
   int radix_bits_total = -1;
   int max_bits_per_pass = 0;
+  int scatter_variant = 0;  // 0 write-combining scatter, 1 tile-staged scatter (A/B)
+  int probe_variant = 0;
   int hash_skip_bits = 0;  // top hash bits already fixed by an upstream owner split
 
   int fail(int code, const char* fmt, ...) const {

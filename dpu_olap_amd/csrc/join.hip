@@ -34,6 +34,7 @@ constexpr int kMaxPasses = 4;
 constexpr uint32_t kScatterLds = kPTile * 8 + kMaxF * 8 + (kMaxF + 4) * 4 + 64;
 
 constexpr int kJBlock = 512;
+constexpr int kJU = 4;                        // 16-B tuple vectors in flight per thread (build / probe)
 constexpr int kSlots = 8192;                  // LDS hash table slots per partition
 constexpr uint32_t kTableCap = kSlots / 4 * 3;  // max build rows (load <= 0.75, hashtable.h:55)
 constexpr uint32_t kTargetBuildRows = kSlots / 2;
@@ -86,10 +87,11 @@ __device__ __forceinline__ TileRange block_tiles(const PassSrc& s) {
   return r;
 }
 
-// Loads one tile: 16 tuples per thread, valid bits in the returned mask.
-template <int SRC, bool WANT_PAYLOAD>
+// Loads one tile: kPTile / BLOCK tuples per thread, valid bits in the returned mask.
+template <int SRC, int BLOCK, bool WANT_PAYLOAD>
 __device__ __forceinline__ uint32_t load_tile(const PassSrc& s, const TileRange& r, uint64_t tile,
-                                              uint32_t (&key)[kTPT], uint32_t (&pay)[kTPT]) {
+                                              uint32_t (&key)[kPTile / BLOCK], uint32_t (&pay)[kPTile / BLOCK]) {
+  constexpr int TPT = kPTile / BLOCK;
   uint32_t mask = 0;
   if (SRC == SRC_COLS) {
     const Loc l = locate(s.v, tile);
@@ -101,15 +103,15 @@ __device__ __forceinline__ uint32_t load_tile(const PassSrc& s, const TileRange&
     const uint32_t rowid0 = (uint32_t)(batch_row0(s.v, l.batch) + r0);
     const bool fast = n == kPTile && ((((uintptr_t)kp) | ((uintptr_t)pp)) & 15) == 0;
     if (fast) {
-      uint4 kv[kTPT / 4], pv[kTPT / 4];
+      uint4 kv[TPT / 4], pv[TPT / 4];
 #pragma unroll
-      for (int j = 0; j < kTPT / 4; ++j) kv[j] = ((const uint4*)kp)[j * kPBlock + threadIdx.x];
+      for (int j = 0; j < TPT / 4; ++j) kv[j] = ((const uint4*)kp)[j * BLOCK + threadIdx.x];
       if (WANT_PAYLOAD && pp) {
 #pragma unroll
-        for (int j = 0; j < kTPT / 4; ++j) pv[j] = ((const uint4*)pp)[j * kPBlock + threadIdx.x];
+        for (int j = 0; j < TPT / 4; ++j) pv[j] = ((const uint4*)pp)[j * BLOCK + threadIdx.x];
       }
 #pragma unroll
-      for (int j = 0; j < kTPT / 4; ++j) {
+      for (int j = 0; j < TPT / 4; ++j) {
         key[4 * j + 0] = kv[j].x;
         key[4 * j + 1] = kv[j].y;
         key[4 * j + 2] = kv[j].z;
@@ -121,7 +123,7 @@ __device__ __forceinline__ uint32_t load_tile(const PassSrc& s, const TileRange&
             pay[4 * j + 2] = pv[j].z;
             pay[4 * j + 3] = pv[j].w;
           } else {
-            const uint32_t i0 = rowid0 + (j * kPBlock + threadIdx.x) * 4;
+            const uint32_t i0 = rowid0 + (j * BLOCK + threadIdx.x) * 4;
             pay[4 * j + 0] = i0;
             pay[4 * j + 1] = i0 + 1;
             pay[4 * j + 2] = i0 + 2;
@@ -129,13 +131,13 @@ __device__ __forceinline__ uint32_t load_tile(const PassSrc& s, const TileRange&
           }
         }
       }
-      mask = 0xFFFFu;
+      mask = (1u << TPT) - 1u;
     } else {
 #pragma unroll
-      for (int j = 0; j < kTPT / 4; ++j) {
+      for (int j = 0; j < TPT / 4; ++j) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const uint32_t idx = (j * kPBlock + threadIdx.x) * 4 + k;
+          const uint32_t idx = (j * BLOCK + threadIdx.x) * 4 + k;
           const bool ok = idx < n;
           key[4 * j + k] = ok ? kp[idx] : 0u;
           if (WANT_PAYLOAD) pay[4 * j + k] = ok ? (pp ? pp[idx] : rowid0 + idx) : 0u;
@@ -145,9 +147,21 @@ __device__ __forceinline__ uint32_t load_tile(const PassSrc& s, const TileRange&
     }
   } else {
     const uint64_t base = r.a + tile * (uint64_t)kPTile;
+    if (base >= r.lo && base + kPTile <= r.hi) {  // whole tile inside the segment (uniform)
+      const uint4* tv = (const uint4*)(s.tuples + base);
 #pragma unroll
-    for (int j = 0; j < kTPT / 2; ++j) {
-      const uint64_t i0 = base + (uint64_t)(j * kPBlock + threadIdx.x) * 2;
+      for (int j = 0; j < TPT / 2; ++j) {
+        const uint4 t = tv[j * BLOCK + threadIdx.x];
+        key[2 * j] = t.x;
+        pay[2 * j] = t.y;
+        key[2 * j + 1] = t.z;
+        pay[2 * j + 1] = t.w;
+      }
+      return (1u << TPT) - 1u;
+    }
+#pragma unroll
+    for (int j = 0; j < TPT / 2; ++j) {
+      const uint64_t i0 = base + (uint64_t)(j * BLOCK + threadIdx.x) * 2;
       uint4 t = make_uint4(0, 0, 0, 0);
       if (i0 < r.hi) t = *(const uint4*)(s.tuples + i0);  // array is padded by 2 tuples
       key[2 * j] = t.x;
@@ -162,24 +176,25 @@ __device__ __forceinline__ uint32_t load_tile(const PassSrc& s, const TileRange&
 }
 
 // ------------------------------------------------------------------ hist
-template <int SRC>
-__global__ __launch_bounds__(kPBlock) void k_part_hist(PassSrc s, uint32_t shift, uint32_t fbits,
-                                                       uint32_t* hist) {
+template <int SRC, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_part_hist(PassSrc s, uint32_t shift, uint32_t fbits,
+                                                     uint32_t* hist) {
+  constexpr int TPT = kPTile / BLOCK;
   __shared__ uint32_t cl[kMaxF];
   const uint32_t F = 1u << fbits;
-  for (uint32_t b = threadIdx.x; b < F; b += kPBlock) cl[b] = 0;
+  for (uint32_t b = threadIdx.x; b < F; b += BLOCK) cl[b] = 0;
   __syncthreads();
   const TileRange r = block_tiles<SRC>(s);
   for (uint64_t tile = r.t0; tile < r.t1; ++tile) {
-    uint32_t key[kTPT], pay[kTPT];
-    const uint32_t mask = load_tile<SRC, false>(s, r, tile, key, pay);
+    uint32_t key[TPT], pay[TPT];
+    const uint32_t mask = load_tile<SRC, BLOCK, false>(s, r, tile, key, pay);
 #pragma unroll
-    for (int i = 0; i < kTPT; ++i) {
+    for (int i = 0; i < TPT; ++i) {
       if (mask & (1u << i)) atomicAdd(&cl[(wang_hash(key[i]) >> shift) & (F - 1)], 1u);
     }
   }
   __syncthreads();
-  for (uint32_t b = threadIdx.x; b < F; b += kPBlock) hist[(uint64_t)blockIdx.x * F + b] = cl[b];
+  for (uint32_t b = threadIdx.x; b < F; b += BLOCK) hist[(uint64_t)blockIdx.x * F + b] = cl[b];
 }
 
 // ------------------------------------------------------------------ scan
@@ -252,7 +267,7 @@ __global__ __launch_bounds__(kPBlock, 4) void k_part_scatter(PassSrc s, uint32_t
   const unsigned wave = threadIdx.x / kWave;
   for (uint64_t tile = r.t0; tile < r.t1; ++tile) {
     uint32_t key[kTPT], pay[kTPT], br[kTPT];
-    const uint32_t mask = load_tile<SRC, true>(s, r, tile, key, pay);
+    const uint32_t mask = load_tile<SRC, kPBlock, true>(s, r, tile, key, pay);
     // (2) bucket + rank inside the bucket
 #pragma unroll
     for (int i = 0; i < kTPT; ++i) {
@@ -320,6 +335,165 @@ __global__ __launch_bounds__(kPBlock, 4) void k_part_scatter(PassSrc s, uint32_t
   }
 }
 
+// ------------------------------------------- scatter, write-combining variant
+// Same contract as k_part_scatter, but every global store is a whole, aligned
+// 64-byte line (8 tuples = one fabric request): per bucket the workgroup keeps the
+// < 8 tuples that do not fill a line yet in LDS ("residue") and emits them together
+// with the next tile's tuples.  Only the first and the last line of a
+// (workgroup, bucket) region can be partial.  1024 threads, one workgroup per CU
+// (LDS: 64 KiB staging + 56 KiB residues + tables); the next tile's loads are
+// issued before the copy-out of the current one.
+//
+// Per bucket (bm[b]): x = start of the bucket's lines in the virtual flush index
+// space of this tile, y = start of the bucket's NEW tuples in `stage`,
+// (z,w) = 64-bit word: absolute, 8-aligned index of residue slot 0 | residue
+// count << 56 | leading slots that belong to the previous workgroup << 60.
+constexpr int kWBlock = 1024;
+constexpr int kWTPT = kPTile / kWBlock;  // 8
+constexpr int kLine = 8;                 // tuples per 64-byte line
+constexpr int kRes = kLine - 1;
+constexpr uint32_t kWcLdsStage = 0;
+constexpr uint32_t kWcLdsRes = kWcLdsStage + kPTile * 8;
+constexpr uint32_t kWcLdsBm = kWcLdsRes + kRes * kMaxF * 8;
+constexpr uint32_t kWcLdsCl = kWcLdsBm + kMaxF * 16;
+constexpr uint32_t kWcLdsL2b = kWcLdsCl + (kMaxF + 4) * 4;
+constexpr uint32_t kWcLdsWtot = kWcLdsL2b + ((kPTile + kRes * kMaxF) / kLine) * 2;
+constexpr uint32_t kWcLds = kWcLdsWtot + (kWBlock / kWave) * 8 + 64;
+
+template <int SRC>
+__global__ __launch_bounds__(kWBlock) void k_part_scatter_wc(PassSrc s, uint32_t shift, uint32_t fbits,
+                                                             const uint32_t* hist,
+                                                             const uint64_t* seg_off_out, uint2* out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint2* stage = (uint2*)(smem + kWcLdsStage);
+  uint2* res = (uint2*)(smem + kWcLdsRes);          // [bucket * kRes + slot]
+  uint4* bm = (uint4*)(smem + kWcLdsBm);
+  uint32_t* cl = (uint32_t*)(smem + kWcLdsCl);
+  uint16_t* l2b = (uint16_t*)(smem + kWcLdsL2b);    // flush line -> bucket
+  uint64_t* wtot = (uint64_t*)(smem + kWcLdsWtot);  // per-wave (count | flush << 32)
+  const uint32_t F = 1u << fbits;
+  const TileRange r = block_tiles<SRC>(s);
+  const unsigned lane = lane_id();
+  const unsigned wave = threadIdx.x / kWave;
+  const uint32_t b_own = threadIdx.x;  // kWBlock >= kMaxF: one bucket per thread
+  const bool owner = b_own < F;
+  if (owner) {
+    const uint64_t off = seg_off_out[(uint64_t)r.seg * F + b_own] + hist[(uint64_t)blockIdx.x * F + b_own];
+    const uint64_t a = off & (kLine - 1);
+    const uint64_t w = (off - a) | (a << 56) | (a << 60);
+    bm[b_own] = make_uint4(0u, 0u, (uint32_t)w, (uint32_t)(w >> 32));
+    cl[b_own] = 0;
+  }
+  __syncthreads();
+  uint32_t key[kWTPT], pay[kWTPT], nkey[kWTPT], npay[kWTPT];
+  uint32_t mask = 0, nmask = 0;
+  if (r.t0 < r.t1) mask = load_tile<SRC, kWBlock, true>(s, r, r.t0, key, pay);
+  for (uint64_t tile = r.t0; tile < r.t1; ++tile) {
+    // (2) bucket + rank of every tuple
+    uint32_t br[kWTPT];
+#pragma unroll
+    for (int i = 0; i < kWTPT; ++i) {
+      br[i] = 0;
+      if (mask & (1u << i)) {
+        const uint32_t b = (wang_hash(key[i]) >> shift) & (F - 1);
+        br[i] = (b << 16) | atomicAdd(&cl[b], 1u);
+      }
+    }
+    __syncthreads();
+    // (3) per bucket: count c, residue rr, lines to flush f; scans of (c, f)
+    uint32_t c = 0, rr = 0, f = 0;
+    uint64_t w64 = 0;
+    if (owner) {
+      c = cl[b_own];
+      const uint4 m = bm[b_own];
+      w64 = ((uint64_t)m.w << 32) | m.z;
+      rr = (uint32_t)(w64 >> 56) & 7u;
+      f = (rr + c) & ~(uint32_t)(kLine - 1);
+    }
+    const uint64_t pair = (uint64_t)c | ((uint64_t)f << 32);
+    uint64_t incl = pair;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+      const uint64_t yv = __shfl_up(incl, o, kWave);
+      if ((int)lane >= o) incl += yv;
+    }
+    if (lane == kWave - 1) wtot[wave] = incl;
+    __syncthreads();
+    uint64_t pre = incl - pair, tot = 0;
+#pragma unroll 1
+    for (int w = 0; w < kWBlock / kWave; ++w) {
+      const uint64_t t = wtot[w];
+      if ((unsigned)w < wave) pre += t;
+      tot += t;
+    }
+    const uint32_t lstart = (uint32_t)pre, vstart = (uint32_t)(pre >> 32);
+    const uint32_t V = (uint32_t)(tot >> 32);
+    if (owner) {
+      bm[b_own] = make_uint4(vstart, lstart, (uint32_t)w64, (uint32_t)(w64 >> 32));
+      cl[b_own] = lstart;  // consecutive buckets -> consecutive banks for the scatter below
+      for (uint32_t q = 0; q < f / kLine; ++q) l2b[vstart / kLine + q] = (uint16_t)b_own;
+    }
+    __syncthreads();
+    // (4) new tuples into the staging area, grouped by bucket, rank order
+#pragma unroll
+    for (int i = 0; i < kWTPT; ++i) {
+      if (mask & (1u << i)) stage[cl[br[i] >> 16] + (br[i] & 0xFFFFu)] = make_uint2(key[i], pay[i]);
+    }
+    // next tile's loads fly during the copy-out
+    nmask = 0;
+    if (tile + 1 < r.t1) nmask = load_tile<SRC, kWBlock, true>(s, r, tile + 1, nkey, npay);
+    __syncthreads();
+    // (5) copy-out: 8 consecutive lanes write one aligned 64-byte line
+#pragma unroll 1
+    for (uint32_t v = threadIdx.x; v < V; v += kWBlock) {
+      const uint32_t b = l2b[v / kLine];
+      const uint4 m = bm[b];
+      const uint64_t w = ((uint64_t)m.w << 32) | m.z;
+      const uint32_t j = v - m.x;
+      const uint32_t r_old = (uint32_t)(w >> 56) & 7u, skip = (uint32_t)(w >> 60) & 7u;
+      if (j >= skip) {
+        const uint2 t = j < r_old ? res[b * kRes + j] : stage[m.y + (j - r_old)];
+        out[(w & 0x00FFFFFFFFFFFFFFull) + j] = t;
+      }
+    }
+    __syncthreads();
+    // (6) what is left of each bucket becomes its residue
+    if (owner) {
+      uint64_t g = w64 & 0x00FFFFFFFFFFFFFFull;
+      uint64_t skip = (w64 >> 60) & 7u;
+      uint32_t r_new;
+      if (f) {
+        const uint32_t nf = f - rr;  // new tuples that were flushed
+        r_new = rr + c - f;
+        for (uint32_t q = 0; q < r_new; ++q) res[b_own * kRes + q] = stage[lstart + nf + q];
+        g += f;
+        skip = 0;
+      } else {
+        for (uint32_t q = 0; q < c; ++q) res[b_own * kRes + rr + q] = stage[lstart + q];
+        r_new = rr + c;
+      }
+      const uint64_t w = g | ((uint64_t)r_new << 56) | (skip << 60);
+      bm[b_own].z = (uint32_t)w;
+      bm[b_own].w = (uint32_t)(w >> 32);
+      cl[b_own] = 0;
+    }
+    __syncthreads();
+    mask = nmask;
+#pragma unroll
+    for (int i = 0; i < kWTPT; ++i) {
+      key[i] = nkey[i];
+      pay[i] = npay[i];
+    }
+  }
+  // tail: the last, partial line of every bucket
+  if (owner) {
+    const uint4 m = bm[b_own];
+    const uint64_t w = ((uint64_t)m.w << 32) | m.z;
+    const uint32_t r_old = (uint32_t)(w >> 56) & 7u, skip = (uint32_t)(w >> 60) & 7u;
+    for (uint32_t j = skip; j < r_old; ++j) out[(w & 0x00FFFFFFFFFFFFFFull) + j] = res[b_own * kRes + j];
+  }
+}
+
 // ------------------------------------------------------------ build + probe
 // counters: [0] missing keys, [1] duplicate build keys, [2] overflowing
 // partitions, [3] max build rows
@@ -327,6 +501,7 @@ __global__ __launch_bounds__(kJBlock, 4) void k_join_probe(const uint2* R, const
                                                            const uint2* L, const uint64_t* l_off,
                                                            uint32_t nparts, uint32_t* out_fk,
                                                            uint32_t* out_y, uint32_t* out_x,
+                                                           uint32_t pair_store,
                                                            unsigned long long* counters) {
   __shared__ uint32_t s_keys[kSlots];
   __shared__ uint32_t s_vals[kSlots];
@@ -346,51 +521,106 @@ __global__ __launch_bounds__(kJBlock, 4) void k_join_probe(const uint2* R, const
     for (uint32_t i = threadIdx.x; i < kSlots; i += kJBlock) s_keys[i] = kEmpty;
     if (threadIdx.x == 0) s_sp[0] = 0;
     __syncthreads();
-    // build: table[pk] = payload (hash_build.c:24-31; value = right payload instead of row index)
-    for (uint32_t i = threadIdx.x; i < (uint32_t)n_r; i += kJBlock) {
-      const uint2 t = R[rlo + i];
-      if (t.x == kEmpty) {
-        s_sp[1] = t.y;
-        if (atomicExch(&s_sp[0], 1u)) ++my_dup;
-      } else {
-        uint32_t slot = wang_hash(t.x) & (kSlots - 1);
-        for (uint32_t step = 0; step < kSlots; ++step) {
-          const uint32_t old = atomicCAS(&s_keys[slot], kEmpty, t.x);
-          if (old == kEmpty || old == t.x) {  // free cell, or equal key overwrites (hashtable.c:133)
-            s_vals[slot] = t.y;
-            if (old == t.x) ++my_dup;
-            break;
+    // build: table[pk] = payload (hash_build.c:24-31; value = right payload instead of row
+    // index).  Tuples are read 16 B per lane (2 tuples) from the 16-B aligned base below the
+    // partition, kJU vectors per thread in flight.
+    {
+      const uint64_t a = rlo & ~1ull;
+      const uint32_t span = (uint32_t)(rhi - a);
+      for (uint32_t base = 0; base < span; base += kJBlock * 2 * kJU) {
+        uint4 v[kJU];
+#pragma unroll
+        for (int u = 0; u < kJU; ++u) {
+          const uint32_t i0 = base + (u * kJBlock + threadIdx.x) * 2;
+          v[u] = make_uint4(0, 0, 0, 0);
+          if (i0 < span) v[u] = *(const uint4*)(R + a + i0);  // arrays are padded by 2 tuples
+        }
+#pragma unroll
+        for (int u = 0; u < kJU; ++u) {
+          const uint64_t i0 = a + base + (uint64_t)(u * kJBlock + threadIdx.x) * 2;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const uint32_t k = h ? v[u].z : v[u].x, val = h ? v[u].w : v[u].y;
+            if (i0 + h < rlo || i0 + h >= rhi) continue;
+            if (k == kEmpty) {
+              s_sp[1] = val;
+              if (atomicExch(&s_sp[0], 1u)) ++my_dup;
+            } else {
+              uint32_t slot = wang_hash(k) & (kSlots - 1);
+              for (uint32_t step = 0; step < kSlots; ++step) {
+                const uint32_t old = atomicCAS(&s_keys[slot], kEmpty, k);
+                if (old == kEmpty || old == k) {  // free cell, or equal key overwrites (hashtable.c:133)
+                  s_vals[slot] = val;
+                  if (old == k) ++my_dup;
+                  break;
+                }
+                slot = (slot + 1) & (kSlots - 1);
+              }
+            }
           }
-          slot = (slot + 1) & (kSlots - 1);
         }
       }
     }
     __syncthreads();
     // probe (hash_probe.c:26-36) fused with the take of the right payload
-    for (uint32_t i = threadIdx.x; i < (uint32_t)n_l; i += kJBlock) {
-      const uint2 t = L[llo + i];
-      uint32_t x = 0;
-      bool hit = false;
-      if (t.x == kEmpty) {
-        hit = s_sp[0] != 0;
-        x = s_sp[1];
-      } else {
-        uint32_t slot = wang_hash(t.x) & (kSlots - 1);
-        for (uint32_t step = 0; step < kSlots; ++step) {
-          const uint32_t k = s_keys[slot];
-          if (k == t.x) {
-            x = s_vals[slot];
-            hit = true;
-            break;
+    {
+      const uint64_t a = llo & ~1ull;
+      const uint64_t span = lhi - a;
+      for (uint64_t base = 0; base < span; base += kJBlock * 2 * kJU) {
+        uint4 v[kJU];
+#pragma unroll
+        for (int u = 0; u < kJU; ++u) {
+          const uint64_t i0 = base + (uint64_t)(u * kJBlock + threadIdx.x) * 2;
+          v[u] = make_uint4(0, 0, 0, 0);
+          if (i0 < span) v[u] = *(const uint4*)(L + a + i0);
+        }
+#pragma unroll
+        for (int u = 0; u < kJU; ++u) {
+          const uint64_t i0 = a + base + (uint64_t)(u * kJBlock + threadIdx.x) * 2;
+          uint32_t xs[2] = {0, 0};
+          bool ok[2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const uint32_t k = h ? v[u].z : v[u].x;
+            ok[h] = i0 + h >= llo && i0 + h < lhi;
+            if (!ok[h]) continue;
+            bool hit = false;
+            if (k == kEmpty) {
+              hit = s_sp[0] != 0;
+              xs[h] = s_sp[1];
+            } else {
+              uint32_t slot = wang_hash(k) & (kSlots - 1);
+              for (uint32_t step = 0; step < kSlots; ++step) {
+                const uint32_t kk = s_keys[slot];
+                if (kk == k) {
+                  xs[h] = s_vals[slot];
+                  hit = true;
+                  break;
+                }
+                if (kk == kEmpty) break;
+                slot = (slot + 1) & (kSlots - 1);
+              }
+            }
+            if (!hit) ++my_miss;
           }
-          if (k == kEmpty) break;
-          slot = (slot + 1) & (kSlots - 1);
+          if (ok[0] && ok[1] && pair_store) {  // i0 is even: 8-byte aligned pair stores
+            *(uint2*)(out_fk + i0) = make_uint2(v[u].x, v[u].z);
+            *(uint2*)(out_y + i0) = make_uint2(v[u].y, v[u].w);
+            *(uint2*)(out_x + i0) = make_uint2(xs[0], xs[1]);
+          } else {
+            if (ok[0]) {
+              out_fk[i0] = v[u].x;
+              out_y[i0] = v[u].y;
+              out_x[i0] = xs[0];
+            }
+            if (ok[1]) {
+              out_fk[i0 + 1] = v[u].z;
+              out_y[i0 + 1] = v[u].w;
+              out_x[i0 + 1] = xs[1];
+            }
+          }
         }
       }
-      if (!hit) ++my_miss;
-      out_fk[llo + i] = t.x;
-      out_y[llo + i] = t.y;
-      out_x[llo + i] = x;
     }
     __syncthreads();
   }
@@ -489,6 +719,11 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
                                     hipFuncAttributeMaxDynamicSharedMemorySize, kScatterLds));
   OLAP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_scatter<SRC_TUPLES>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, kScatterLds));
+  OLAP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_scatter_wc<SRC_COLS>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, kWcLds));
+  OLAP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_scatter_wc<SRC_TUPLES>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, kWcLds));
+  const bool wc = ctx->scatter_variant == 0;  // write-combining scatter: 1 workgroup of 1024 per CU
   for (int i = 0; i < plan.passes; ++i) {
     const uint32_t fbits = plan.bits[i];
     const uint64_t F = 1ull << fbits;
@@ -498,7 +733,7 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
     uint64_t blocks, bseg;
     if (i == 0) {
       const uint64_t tiles = cs.view.total_units;
-      uint64_t nb = (uint64_t)ctx->compute_units * 2;
+      uint64_t nb = (uint64_t)ctx->compute_units * (wc ? 1 : 2);
       if (nb > tiles) nb = tiles;
       if (nb == 0) nb = 1;
       src.tiles_per_block = (tiles + nb - 1) / nb;
@@ -521,9 +756,9 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
     {
       PhaseScope ps(ctx, PH_PART_HIST);
       if (i == 0)
-        hipLaunchKernelGGL((k_part_hist<SRC_COLS>), dim3((unsigned)blocks), dim3(kPBlock), 0, ctx->stream, src, shift, fbits, hist);
+        hipLaunchKernelGGL((k_part_hist<SRC_COLS, kWBlock>), dim3((unsigned)blocks), dim3(kWBlock), 0, ctx->stream, src, shift, fbits, hist);
       else
-        hipLaunchKernelGGL((k_part_hist<SRC_TUPLES>), dim3((unsigned)blocks), dim3(kPBlock), 0, ctx->stream, src, shift, fbits, hist);
+        hipLaunchKernelGGL((k_part_hist<SRC_TUPLES, kWBlock>), dim3((unsigned)blocks), dim3(kWBlock), 0, ctx->stream, src, shift, fbits, hist);
       OLAP_HIP(ctx, hipGetLastError());
     }
     {
@@ -534,7 +769,13 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
     }
     {
       PhaseScope ps(ctx, PH_PART_SCATTER);
-      if (i == 0)
+      if (wc && i == 0)
+        hipLaunchKernelGGL((k_part_scatter_wc<SRC_COLS>), dim3((unsigned)blocks), dim3(kWBlock), kWcLds, ctx->stream,
+                           src, shift, fbits, (const uint32_t*)hist, (const uint64_t*)seg_out, out);
+      else if (wc)
+        hipLaunchKernelGGL((k_part_scatter_wc<SRC_TUPLES>), dim3((unsigned)blocks), dim3(kWBlock), kWcLds, ctx->stream,
+                           src, shift, fbits, (const uint32_t*)hist, (const uint64_t*)seg_out, out);
+      else if (i == 0)
         hipLaunchKernelGGL((k_part_scatter<SRC_COLS>), dim3((unsigned)blocks), dim3(kPBlock), kScatterLds, ctx->stream,
                            src, shift, fbits, (const uint32_t*)hist, (const uint64_t*)seg_out, out);
       else
@@ -605,7 +846,8 @@ static int join_once(olap_ctx* ctx, const uint32_t* const* lfk, const uint32_t* 
     uint64_t grid = (uint64_t)ctx->compute_units * 8;
     if (grid > P) grid = P;
     hipLaunchKernelGGL(k_join_probe, dim3((unsigned)grid), dim3(kJBlock), 0, ctx->stream, (const uint2*)Rt,
-                       (const uint64_t*)r_off, (const uint2*)Lt, (const uint64_t*)l_off, P, d_fk, d_y, d_x, d_cnt);
+                       (const uint64_t*)r_off, (const uint2*)Lt, (const uint64_t*)l_off, P, d_fk, d_y, d_x,
+                       (uint32_t)(((((uintptr_t)d_fk) | ((uintptr_t)d_y) | ((uintptr_t)d_x)) & 7) == 0), d_cnt);
     OLAP_HIP(ctx, hipGetLastError());
   }
   OLAP_HIP(ctx, hipMemcpyAsync(counters, d_cnt, 32, hipMemcpyDeviceToHost, ctx->stream));
@@ -636,6 +878,20 @@ static int join_once(olap_ctx* ctx, const uint32_t* const* lfk, const uint32_t* 
 using namespace olap;
 
 extern "C" {
+
+int olap_set_tuning(olap_ctx* ctx, const char* key, int value) {
+  if (!ctx || !key) return OLAP_ERR_INVALID;
+  if (!std::strcmp(key, "scatter_variant")) {
+    if (value < 0 || value > 1) return ctx->fail(OLAP_ERR_INVALID, "scatter_variant must be 0 (write-combining) or 1 (tile-staged)");
+    ctx->scatter_variant = value;
+    return OLAP_OK;
+  }
+  if (!std::strcmp(key, "probe_variant")) {
+    ctx->probe_variant = value;
+    return OLAP_OK;
+  }
+  return ctx->fail(OLAP_ERR_INVALID, "unknown tuning key '%s'", key);
+}
 
 int olap_join_set_hash_skip_bits(olap_ctx* ctx, int bits) {
   if (!ctx) return OLAP_ERR_INVALID;

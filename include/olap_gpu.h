@@ -186,6 +186,9 @@ int olap_join_u32(olap_ctx* ctx, const uint32_t* const* left_fk_ptrs,
 /* Tuning knobs (0 = default).  radix_bits_total < 0 keeps the automatic choice
  * ceil(log2(right_rows / 4096)). */
 int olap_join_configure(olap_ctx* ctx, int radix_bits_total, int max_bits_per_pass);
+/* Kernel-variant switches for A/B measurements in one process ("scatter_variant":
+ * 0 = write-combining scatter (default), 1 = tile-staged scatter). */
+int olap_set_tuning(olap_ctx* ctx, const char* key, int value);
 /* Multi-GPU: when the inputs of this context were already split by the top
  * `bits` bits of wang_hash(key) (olap_partition_u32 with nr_partitions = #GPUs,
  * one partition per GPU), all keys here share those bits; the join's own radix

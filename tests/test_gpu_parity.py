@@ -259,6 +259,51 @@ def test_join_vs_arrow_golden(dev, golden, case, cfg, device):
         assert sum(stats["radix_bits"]) == cfg["bits"]
 
 
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("cfg", [dict(), dict(bits=12, max_bits=4), dict(bits=20)])
+def test_join_scatter_variants_agree(dev, golden, variant, cfg):
+    """Both scatter kernels (0 = write-combining, 1 = tile-staged) give the golden table, also
+    with the 10+10-bit plan of the SF=2048 benchmark (tiny partitions here)."""
+    dev.set_tuning("scatter_variant", variant)
+    try:
+        for case in ("a", "b"):
+            lf = split_batches(golden[f"join_{case}_fk"], golden[f"join_{case}_left_rows"])
+            ly = split_batches(golden[f"join_{case}_y"], golden[f"join_{case}_left_rows"])
+            rp = split_batches(golden[f"join_{case}_pk"], golden[f"join_{case}_right_rows"])
+            rx = split_batches(golden[f"join_{case}_x"], golden[f"join_{case}_right_rows"])
+            (fk, y, x), _ = _join_sorted(dev, lf, ly, rp, rx, device=True, **cfg)
+            np.testing.assert_array_equal(fk, golden[f"join_{case}_out_fk"])
+            np.testing.assert_array_equal(y, golden[f"join_{case}_out_y"])
+            np.testing.assert_array_equal(x, golden[f"join_{case}_out_x"])
+    finally:
+        dev.set_tuning("scatter_variant", 0)
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_partition_variants_vs_oracle_multiset(dev, variant):
+    o = _ops()
+    rng = np.random.default_rng(11)
+    keys = [rng.integers(0, 1 << 32, size=s, dtype=np.uint32) for s in (300000, 77777, 5)]
+    # heavy skew: one hot key and one hot bucket
+    keys[0][:100000] = 12345
+    pay = [np.arange(k.size, dtype=np.uint32) for k in keys]
+    dev.set_tuning("scatter_variant", variant)
+    try:
+        parts = o.PartitionGpu(dev, list(zip(keys, pay)), 1024).Prepare().Run()
+    finally:
+        dev.set_tuning("scatter_variant", 0)
+    allk, allp = np.concatenate(keys), np.concatenate(pay)
+    bucket = oracle.wang_hash_np(allk) >> np.uint32(22)
+    gk = np.concatenate([k for k, _ in parts])
+    gp = np.concatenate([p for _, p in parts])
+    gb = np.concatenate([np.full(k.size, i, dtype=np.uint32) for i, (k, _) in enumerate(parts)])
+    np.testing.assert_array_equal(oracle.wang_hash_np(gk) >> np.uint32(22), gb)
+    e = sort_rows(bucket, allk, allp)
+    g = sort_rows(gb, gk, gp)
+    for a, b in zip(e, g):
+        np.testing.assert_array_equal(a, b)
+
+
 def test_join_large_test_shape_vs_oracle(dev):
     """JoinTest.LargeTest: 128 x 64Ki rows per side, generator data; all columns equal after
     sort by (fk, y); row count == left rows."""
