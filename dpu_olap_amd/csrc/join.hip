@@ -360,10 +360,24 @@ constexpr uint32_t kWcLdsL2b = kWcLdsCl + (kMaxF + 4) * 4;
 constexpr uint32_t kWcLdsWtot = kWcLdsL2b + ((kPTile + kRes * kMaxF) / kLine) * 2;
 constexpr uint32_t kWcLds = kWcLdsWtot + (kWBlock / kWave) * 8 + 64;
 
-template <int SRC>
+// Capacity mode (CAPM, last pass only, one workgroup per input segment): no histogram
+// pre-pass.  Output bucket (seg, b) owns the fixed region [p * cap, (p + 1) * cap) with
+// p = seg * F + b; the workgroup reports how many tuples landed there (cnt[p]) and where
+// the partition starts in the dense numbering (dense[p]).  A bucket that would outgrow
+// its region raises *overflow and drops the excess; the host then reruns the join with
+// exact (histogram) partitioning.
+struct CapOut {
+  uint32_t cap;       // tuples per region, multiple of kLine
+  uint32_t* cnt;      // [n_seg * F]
+  uint64_t* dense;    // [n_seg * F]
+  unsigned long long* overflow;
+};
+
+template <int SRC, bool CAPM>
 __global__ __launch_bounds__(kWBlock) void k_part_scatter_wc(PassSrc s, uint32_t shift, uint32_t fbits,
                                                              const uint32_t* hist,
-                                                             const uint64_t* seg_off_out, uint2* out) {
+                                                             const uint64_t* seg_off_out, uint2* out,
+                                                             CapOut co) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint2* stage = (uint2*)(smem + kWcLdsStage);
   uint2* res = (uint2*)(smem + kWcLdsRes);          // [bucket * kRes + slot]
@@ -377,8 +391,15 @@ __global__ __launch_bounds__(kWBlock) void k_part_scatter_wc(PassSrc s, uint32_t
   const unsigned wave = threadIdx.x / kWave;
   const uint32_t b_own = threadIdx.x;  // kWBlock >= kMaxF: one bucket per thread
   const bool owner = b_own < F;
+  uint64_t region = 0;  // CAPM: first tuple index of this thread's bucket region
   if (owner) {
-    const uint64_t off = seg_off_out[(uint64_t)r.seg * F + b_own] + hist[(uint64_t)blockIdx.x * F + b_own];
+    uint64_t off;
+    if (CAPM) {
+      region = ((uint64_t)r.seg * F + b_own) * co.cap;
+      off = region;
+    } else {
+      off = seg_off_out[(uint64_t)r.seg * F + b_own] + hist[(uint64_t)blockIdx.x * F + b_own];
+    }
     const uint64_t a = off & (kLine - 1);
     const uint64_t w = (off - a) | (a << 56) | (a << 60);
     bm[b_own] = make_uint4(0u, 0u, (uint32_t)w, (uint32_t)(w >> 32));
@@ -401,14 +422,19 @@ __global__ __launch_bounds__(kWBlock) void k_part_scatter_wc(PassSrc s, uint32_t
     }
     __syncthreads();
     // (3) per bucket: count c, residue rr, lines to flush f; scans of (c, f)
-    uint32_t c = 0, rr = 0, f = 0;
+    uint32_t c = 0, c_app = 0, rr = 0, f = 0;
     uint64_t w64 = 0;
     if (owner) {
       c = cl[b_own];
       const uint4 m = bm[b_own];
       w64 = ((uint64_t)m.w << 32) | m.z;
       rr = (uint32_t)(w64 >> 56) & 7u;
-      f = (rr + c) & ~(uint32_t)(kLine - 1);
+      c_app = c;
+      if (CAPM && (w64 & 0x00FFFFFFFFFFFFFFull) - region + rr + c > co.cap) {
+        c_app = 0;  // region full: drop this tile's tuples of the bucket, report
+        if (c) atomicAdd(co.overflow, 1ull);
+      }
+      f = (rr + c_app) & ~(uint32_t)(kLine - 1);
     }
     const uint64_t pair = (uint64_t)c | ((uint64_t)f << 32);
     uint64_t incl = pair;
@@ -443,17 +469,21 @@ __global__ __launch_bounds__(kWBlock) void k_part_scatter_wc(PassSrc s, uint32_t
     nmask = 0;
     if (tile + 1 < r.t1) nmask = load_tile<SRC, kWBlock, true>(s, r, tile + 1, nkey, npay);
     __syncthreads();
-    // (5) copy-out: 8 consecutive lanes write one aligned 64-byte line
+    // (5) copy-out: 4 consecutive lanes write one aligned 64-byte line, 16 B (2 tuples) each
 #pragma unroll 1
-    for (uint32_t v = threadIdx.x; v < V; v += kWBlock) {
+    for (uint32_t v = threadIdx.x * 2; v < V; v += kWBlock * 2) {
       const uint32_t b = l2b[v / kLine];
       const uint4 m = bm[b];
       const uint64_t w = ((uint64_t)m.w << 32) | m.z;
-      const uint32_t j = v - m.x;
+      const uint32_t j = v - m.x;  // even
       const uint32_t r_old = (uint32_t)(w >> 56) & 7u, skip = (uint32_t)(w >> 60) & 7u;
+      const uint2 t0 = j < r_old ? res[b * kRes + j] : stage[m.y + (j - r_old)];
+      const uint2 t1 = j + 1 < r_old ? res[b * kRes + j + 1] : stage[m.y + (j + 1 - r_old)];
+      uint2* dst = out + (w & 0x00FFFFFFFFFFFFFFull) + j;
       if (j >= skip) {
-        const uint2 t = j < r_old ? res[b * kRes + j] : stage[m.y + (j - r_old)];
-        out[(w & 0x00FFFFFFFFFFFFFFull) + j] = t;
+        *(uint4*)dst = make_uint4(t0.x, t0.y, t1.x, t1.y);
+      } else if (j + 1 >= skip) {
+        dst[1] = t1;
       }
     }
     __syncthreads();
@@ -464,13 +494,13 @@ __global__ __launch_bounds__(kWBlock) void k_part_scatter_wc(PassSrc s, uint32_t
       uint32_t r_new;
       if (f) {
         const uint32_t nf = f - rr;  // new tuples that were flushed
-        r_new = rr + c - f;
+        r_new = rr + c_app - f;
         for (uint32_t q = 0; q < r_new; ++q) res[b_own * kRes + q] = stage[lstart + nf + q];
         g += f;
         skip = 0;
       } else {
-        for (uint32_t q = 0; q < c; ++q) res[b_own * kRes + rr + q] = stage[lstart + q];
-        r_new = rr + c;
+        for (uint32_t q = 0; q < c_app; ++q) res[b_own * kRes + rr + q] = stage[lstart + q];
+        r_new = rr + c_app;
       }
       const uint64_t w = g | ((uint64_t)r_new << 56) | (skip << 60);
       bm[b_own].z = (uint32_t)w;
@@ -486,32 +516,67 @@ __global__ __launch_bounds__(kWBlock) void k_part_scatter_wc(PassSrc s, uint32_t
     }
   }
   // tail: the last, partial line of every bucket
+  uint64_t count = 0;
   if (owner) {
     const uint4 m = bm[b_own];
     const uint64_t w = ((uint64_t)m.w << 32) | m.z;
     const uint32_t r_old = (uint32_t)(w >> 56) & 7u, skip = (uint32_t)(w >> 60) & 7u;
     for (uint32_t j = skip; j < r_old; ++j) out[(w & 0x00FFFFFFFFFFFFFFull) + j] = res[b_own * kRes + j];
+    count = (w & 0x00FFFFFFFFFFFFFFull) - region + r_old;
+  }
+  if (CAPM) {  // partition sizes and dense starts (exclusive scan over this segment's buckets)
+    uint64_t incl = count;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+      const uint64_t yv = __shfl_up(incl, o, kWave);
+      if ((int)lane >= o) incl += yv;
+    }
+    __syncthreads();
+    if (lane == kWave - 1) wtot[wave] = incl;
+    __syncthreads();
+    uint64_t pre = incl - count;
+#pragma unroll 1
+    for (unsigned w = 0; w < wave; ++w) pre += wtot[w];
+    if (owner) {
+      co.cnt[(uint64_t)r.seg * F + b_own] = (uint32_t)count;
+      co.dense[(uint64_t)r.seg * F + b_own] = r.lo + pre;
+    }
   }
 }
 
 // ------------------------------------------------------------ build + probe
 // counters: [0] missing keys, [1] duplicate build keys, [2] overflowing
 // partitions, [3] max build rows
-__global__ __launch_bounds__(kJBlock, 4) void k_join_probe(const uint2* R, const uint64_t* r_off,
-                                                           const uint2* L, const uint64_t* l_off,
-                                                           uint32_t nparts, uint32_t* out_fk,
-                                                           uint32_t* out_y, uint32_t* out_x,
-                                                           uint32_t pair_store,
+// A partitioned side: exact layout (cap == 0: partition p = [off[p], off[p+1])) or
+// capacity layout (partition p = [p * cap, p * cap + cnt[p]), dense start dense[p]).
+struct PartView {
+  const uint2* t;
+  const uint64_t* off;
+  const uint32_t* cnt;
+  const uint64_t* dense;
+  uint32_t cap;
+};
+
+__global__ __launch_bounds__(kJBlock, 4) void k_join_probe(PartView RV, PartView LV, uint32_t nparts,
+                                                           uint32_t* out_fk, uint32_t* out_y,
+                                                           uint32_t* out_x, uint32_t pair_store_ok,
                                                            unsigned long long* counters) {
+  const uint2* R = RV.t;
+  const uint2* L = LV.t;
   __shared__ uint32_t s_keys[kSlots];
   __shared__ uint32_t s_vals[kSlots];
   __shared__ uint32_t s_sp[2];  // the one key equal to the empty marker: {present, value}
   uint32_t my_miss = 0, my_dup = 0;
   uint64_t my_max = 0;
   for (uint32_t p = blockIdx.x; p < nparts; p += gridDim.x) {
-    const uint64_t rlo = r_off[p], rhi = r_off[p + 1];
-    const uint64_t llo = l_off[p], lhi = l_off[p + 1];
+    const uint64_t rlo = RV.cap ? (uint64_t)p * RV.cap : RV.off[p];
+    const uint64_t rhi = RV.cap ? rlo + RV.cnt[p] : RV.off[p + 1];
+    const uint64_t llo = LV.cap ? (uint64_t)p * LV.cap : LV.off[p];
+    const uint64_t lhi = LV.cap ? llo + LV.cnt[p] : LV.off[p + 1];
     const uint64_t n_r = rhi - rlo, n_l = lhi - llo;
+    // output rows are dense: tuple at sparse index i goes to row i + delta
+    const uint64_t delta = (LV.cap ? LV.dense[p] : llo) - llo;
+    const uint32_t pair_store = pair_store_ok && (delta & 1) == 0;
     if (n_r > my_max) my_max = n_r;
     if (n_l == 0) continue;
     if (n_r > kTableCap) {
@@ -604,19 +669,21 @@ __global__ __launch_bounds__(kJBlock, 4) void k_join_probe(const uint2* R, const
             if (!hit) ++my_miss;
           }
           if (ok[0] && ok[1] && pair_store) {  // i0 is even: 8-byte aligned pair stores
-            *(uint2*)(out_fk + i0) = make_uint2(v[u].x, v[u].z);
-            *(uint2*)(out_y + i0) = make_uint2(v[u].y, v[u].w);
-            *(uint2*)(out_x + i0) = make_uint2(xs[0], xs[1]);
+            const uint64_t o = i0 + delta;
+            *(uint2*)(out_fk + o) = make_uint2(v[u].x, v[u].z);
+            *(uint2*)(out_y + o) = make_uint2(v[u].y, v[u].w);
+            *(uint2*)(out_x + o) = make_uint2(xs[0], xs[1]);
           } else {
+            const uint64_t o = i0 + delta;
             if (ok[0]) {
-              out_fk[i0] = v[u].x;
-              out_y[i0] = v[u].y;
-              out_x[i0] = xs[0];
+              out_fk[o] = v[u].x;
+              out_y[o] = v[u].y;
+              out_x[o] = xs[0];
             }
             if (ok[1]) {
-              out_fk[i0 + 1] = v[u].z;
-              out_y[i0 + 1] = v[u].w;
-              out_x[i0 + 1] = xs[1];
+              out_fk[o + 1] = v[u].z;
+              out_y[o + 1] = v[u].w;
+              out_x[o + 1] = xs[1];
             }
           }
         }
@@ -699,13 +766,35 @@ static uint64_t side_scratch_bytes(const olap_ctx* ctx, uint64_t rows, const Pas
     bytes += align_up((n_seg * F + 1) * 8, 256);     // segment table
     n_seg *= F;
   }
+  bytes += align_up(n_seg * 4, 256) + align_up(n_seg * 8, 256);  // capacity-layout tables
   return bytes + 4096;
 }
 
 // Runs all passes of one side.  `cs` views the key/payload columns with unit_rows = kPTile.
+struct SideOut {
+  uint64_t* off = nullptr;   // exact layout: [P + 1]
+  uint32_t cap = 0;          // capacity layout: tuples per region (0 = exact)
+  uint32_t* cnt = nullptr;   // capacity layout: [P]
+  uint64_t* dense = nullptr; // capacity layout: [P]
+};
+
+static uint32_t region_cap(uint64_t rows, uint64_t P) {
+  const uint64_t avg = (rows + P - 1) / P;
+  return (uint32_t)align_up(avg + avg / 8 + 64, kLine);
+}
+
+// The last pass may skip its histogram (capacity layout) when every workgroup owns whole
+// input segments and there are enough of them to fill the chip.
+static bool capacity_eligible(const olap_ctx* ctx, uint64_t rows, const PassPlan& plan) {
+  if (!ctx->capacity_mode || ctx->scatter_variant != 0 || plan.passes < 2) return false;
+  const uint64_t P = 1ull << plan.total_bits;
+  const uint64_t n_seg_last = P >> plan.bits[plan.passes - 1];
+  return n_seg_last >= (uint64_t)ctx->compute_units && rows / P >= 512;
+}
+
 static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, const PassPlan& plan,
                           uint32_t skip_bits, uint2* tmp0, uint2* tmp1, uint2* final_tuples,
-                          uint64_t** final_off) {
+                          bool capm, unsigned long long* d_overflow, SideOut* so) {
   const uint64_t rows = cs.view.total_rows;
   PassSrc src{};
   src.v = cs.view;
@@ -719,9 +808,11 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
                                     hipFuncAttributeMaxDynamicSharedMemorySize, kScatterLds));
   OLAP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_scatter<SRC_TUPLES>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, kScatterLds));
-  OLAP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_scatter_wc<SRC_COLS>),
+  OLAP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_scatter_wc<SRC_COLS, false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, kWcLds));
-  OLAP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_scatter_wc<SRC_TUPLES>),
+  OLAP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_scatter_wc<SRC_TUPLES, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, kWcLds));
+  OLAP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_scatter_wc<SRC_TUPLES, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, kWcLds));
   const bool wc = ctx->scatter_variant == 0;  // write-combining scatter: 1 workgroup of 1024 per CU
   for (int i = 0; i < plan.passes; ++i) {
@@ -742,7 +833,7 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
       if (blocks == 0) blocks = 1;
       bseg = blocks;
     } else {
-      bseg = seg_blocks(ctx, n_seg);
+      bseg = (capm && i == plan.passes - 1) ? 1 : seg_blocks(ctx, n_seg);
       blocks = n_seg * bseg;
       src.tuples = in_tuples;
       src.seg_off = seg_in;
@@ -750,6 +841,18 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
       src.blocks_per_seg = (uint32_t)bseg;
     }
     if (blocks > 0x7FFFFFFFull) return ctx->fail(OLAP_ERR_INVALID, "partition grid too large");
+    if (capm && i == plan.passes - 1) {  // capacity layout: scatter only
+      so->cap = region_cap(rows, n_seg * F);
+      so->cnt = (uint32_t*)ws_alloc(ctx, n_seg * F * 4);
+      so->dense = (uint64_t*)ws_alloc(ctx, n_seg * F * 8);
+      if (!so->cnt || !so->dense) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (capacity tables)");
+      PhaseScope ps(ctx, PH_PART_SCATTER);
+      CapOut co{so->cap, so->cnt, so->dense, d_overflow};
+      hipLaunchKernelGGL((k_part_scatter_wc<SRC_TUPLES, true>), dim3((unsigned)blocks), dim3(kWBlock), kWcLds, ctx->stream,
+                         src, shift, fbits, (const uint32_t*)nullptr, (const uint64_t*)nullptr, out, co);
+      OLAP_HIP(ctx, hipGetLastError());
+      return OLAP_OK;
+    }
     uint32_t* hist = (uint32_t*)ws_alloc(ctx, blocks * F * 4);
     uint64_t* seg_out = (uint64_t*)ws_alloc(ctx, (n_seg * F + 1) * 8);
     if (!hist || !seg_out) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (partition pass %d)", i);
@@ -770,11 +873,11 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
     {
       PhaseScope ps(ctx, PH_PART_SCATTER);
       if (wc && i == 0)
-        hipLaunchKernelGGL((k_part_scatter_wc<SRC_COLS>), dim3((unsigned)blocks), dim3(kWBlock), kWcLds, ctx->stream,
-                           src, shift, fbits, (const uint32_t*)hist, (const uint64_t*)seg_out, out);
+        hipLaunchKernelGGL((k_part_scatter_wc<SRC_COLS, false>), dim3((unsigned)blocks), dim3(kWBlock), kWcLds, ctx->stream,
+                           src, shift, fbits, (const uint32_t*)hist, (const uint64_t*)seg_out, out, CapOut{});
       else if (wc)
-        hipLaunchKernelGGL((k_part_scatter_wc<SRC_TUPLES>), dim3((unsigned)blocks), dim3(kWBlock), kWcLds, ctx->stream,
-                           src, shift, fbits, (const uint32_t*)hist, (const uint64_t*)seg_out, out);
+        hipLaunchKernelGGL((k_part_scatter_wc<SRC_TUPLES, false>), dim3((unsigned)blocks), dim3(kWBlock), kWcLds, ctx->stream,
+                           src, shift, fbits, (const uint32_t*)hist, (const uint64_t*)seg_out, out, CapOut{});
       else if (i == 0)
         hipLaunchKernelGGL((k_part_scatter<SRC_COLS>), dim3((unsigned)blocks), dim3(kPBlock), kScatterLds, ctx->stream,
                            src, shift, fbits, (const uint32_t*)hist, (const uint64_t*)seg_out, out);
@@ -787,7 +890,7 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
     seg_in = seg_out;
     n_seg *= F;
   }
-  *final_off = const_cast<uint64_t*>(seg_in);
+  so->off = const_cast<uint64_t*>(seg_in);
   return OLAP_OK;
 }
 
@@ -803,7 +906,8 @@ static int check_side(olap_ctx* ctx, const void* keys, const uint64_t* rows, uin
 static int join_once(olap_ctx* ctx, const uint32_t* const* lfk, const uint32_t* const* ly, const uint64_t* lrows,
                      uint64_t lnb, const uint32_t* const* rpk, const uint32_t* const* rx, const uint64_t* rrows,
                      uint64_t rnb, int in_mem, uint32_t* out_fk, uint32_t* out_y, uint32_t* out_x, int out_mem,
-                     uint64_t NL, uint64_t NR, uint32_t total_bits, olap_join_stats* st, unsigned long long counters[4]) {
+                     uint64_t NL, uint64_t NR, uint32_t total_bits, bool allow_capacity, olap_join_stats* st,
+                     unsigned long long counters[5]) {
   PassPlan plan;
   OLAP_TRY(make_plan(ctx, total_bits, &plan));
   if (plan.total_bits + (uint32_t)ctx->hash_skip_bits > 32)
@@ -813,9 +917,13 @@ static int join_once(olap_ctx* ctx, const uint32_t* const* lfk, const uint32_t* 
   const void* const* lcols[2] = {(const void* const*)lfk, (const void* const*)ly};
   const void* const* rcols[2] = {(const void* const*)rpk, (const void* const*)rx};
   const uint64_t maxN = NL > NR ? NL : NR;
+  const bool lcap = allow_capacity && capacity_eligible(ctx, NL, plan);
+  const bool rcap = allow_capacity && capacity_eligible(ctx, NR, plan);
+  const uint64_t lt_tuples = lcap ? (uint64_t)P * region_cap(NL, P) : NL;
+  const uint64_t rt_tuples = rcap ? (uint64_t)P * region_cap(NR, P) : NR;
   uint64_t need = column_set_bytes(lrows, lnb, 2, eb, in_mem) + column_set_bytes(rrows, rnb, 2, eb, in_mem) +
                   side_scratch_bytes(ctx, NL, plan) + side_scratch_bytes(ctx, NR, plan) +
-                  align_up((NL + 2) * 8, 256) + align_up((NR + 2) * 8, 256) + 8192;
+                  align_up((lt_tuples + 2) * 8, 256) + align_up((rt_tuples + 2) * 8, 256) + 8192;
   if (plan.passes >= 2) need += align_up((maxN + 2) * 8, 256);
   if (plan.passes >= 3) need += align_up((maxN + 2) * 8, 256);
   if (out_mem == OLAP_MEM_HOST) need += 3 * align_up(NL * 4 + 4, 256);
@@ -826,9 +934,9 @@ static int join_once(olap_ctx* ctx, const uint32_t* const* lfk, const uint32_t* 
   OLAP_TRY(build_column_set(ctx, rcols, 2, eb, rrows, rnb, in_mem, kPTile, &rcs));
   uint2* tmp0 = plan.passes >= 2 ? (uint2*)ws_alloc(ctx, (maxN + 2) * 8) : nullptr;
   uint2* tmp1 = plan.passes >= 3 ? (uint2*)ws_alloc(ctx, (maxN + 2) * 8) : nullptr;
-  uint2* Lt = (uint2*)ws_alloc(ctx, (NL + 2) * 8);
-  uint2* Rt = (uint2*)ws_alloc(ctx, (NR + 2) * 8);
-  unsigned long long* d_cnt = (unsigned long long*)ws_alloc(ctx, 32);
+  uint2* Lt = (uint2*)ws_alloc(ctx, (lt_tuples + 2) * 8);
+  uint2* Rt = (uint2*)ws_alloc(ctx, (rt_tuples + 2) * 8);
+  unsigned long long* d_cnt = (unsigned long long*)ws_alloc(ctx, 40);
   uint32_t *d_fk = out_fk, *d_y = out_y, *d_x = out_x;
   if (out_mem == OLAP_MEM_HOST) {
     d_fk = (uint32_t*)ws_alloc(ctx, NL * 4 + 4);
@@ -837,22 +945,23 @@ static int join_once(olap_ctx* ctx, const uint32_t* const* lfk, const uint32_t* 
   }
   if ((plan.passes >= 2 && !tmp0) || (plan.passes >= 3 && !tmp1) || !Lt || !Rt || !d_cnt || !d_fk || !d_y || !d_x)
     return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (join buffers)");
-  OLAP_HIP(ctx, hipMemsetAsync(d_cnt, 0, 32, ctx->stream));
-  uint64_t *l_off = nullptr, *r_off = nullptr;
-  OLAP_TRY(partition_side(ctx, lcs, true, plan, (uint32_t)ctx->hash_skip_bits, tmp0, tmp1, Lt, &l_off));
-  OLAP_TRY(partition_side(ctx, rcs, true, plan, (uint32_t)ctx->hash_skip_bits, tmp0, tmp1, Rt, &r_off));
+  OLAP_HIP(ctx, hipMemsetAsync(d_cnt, 0, 40, ctx->stream));
+  SideOut lso, rso;
+  OLAP_TRY(partition_side(ctx, lcs, true, plan, (uint32_t)ctx->hash_skip_bits, tmp0, tmp1, Lt, lcap, d_cnt + 4, &lso));
+  OLAP_TRY(partition_side(ctx, rcs, true, plan, (uint32_t)ctx->hash_skip_bits, tmp0, tmp1, Rt, rcap, d_cnt + 4, &rso));
   {
     PhaseScope ps(ctx, PH_JOIN_PROBE);
     uint64_t grid = (uint64_t)ctx->compute_units * 8;
     if (grid > P) grid = P;
-    hipLaunchKernelGGL(k_join_probe, dim3((unsigned)grid), dim3(kJBlock), 0, ctx->stream, (const uint2*)Rt,
-                       (const uint64_t*)r_off, (const uint2*)Lt, (const uint64_t*)l_off, P, d_fk, d_y, d_x,
+    const PartView rv{Rt, rso.off, rso.cnt, rso.dense, rso.cap};
+    const PartView lv{Lt, lso.off, lso.cnt, lso.dense, lso.cap};
+    hipLaunchKernelGGL(k_join_probe, dim3((unsigned)grid), dim3(kJBlock), 0, ctx->stream, rv, lv, P, d_fk, d_y, d_x,
                        (uint32_t)(((((uintptr_t)d_fk) | ((uintptr_t)d_y) | ((uintptr_t)d_x)) & 7) == 0), d_cnt);
     OLAP_HIP(ctx, hipGetLastError());
   }
-  OLAP_HIP(ctx, hipMemcpyAsync(counters, d_cnt, 32, hipMemcpyDeviceToHost, ctx->stream));
+  OLAP_HIP(ctx, hipMemcpyAsync(counters, d_cnt, 40, hipMemcpyDeviceToHost, ctx->stream));
   OLAP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if (out_mem == OLAP_MEM_HOST && counters[2] == 0 && counters[0] == 0 && NL) {
+  if (out_mem == OLAP_MEM_HOST && counters[2] == 0 && counters[0] == 0 && counters[4] == 0 && NL) {
     PhaseScope ps(ctx, PH_COPY_FROM);
     OLAP_HIP(ctx, hipMemcpyAsync(out_fk, d_fk, NL * 4, hipMemcpyDeviceToHost, ctx->stream));
     OLAP_HIP(ctx, hipMemcpyAsync(out_y, d_y, NL * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -884,6 +993,10 @@ int olap_set_tuning(olap_ctx* ctx, const char* key, int value) {
   if (!std::strcmp(key, "scatter_variant")) {
     if (value < 0 || value > 1) return ctx->fail(OLAP_ERR_INVALID, "scatter_variant must be 0 (write-combining) or 1 (tile-staged)");
     ctx->scatter_variant = value;
+    return OLAP_OK;
+  }
+  if (!std::strcmp(key, "capacity_mode")) {
+    ctx->capacity_mode = value != 0;
     return OLAP_OK;
   }
   if (!std::strcmp(key, "probe_variant")) {
@@ -941,11 +1054,16 @@ int olap_join_u32(olap_ctx* ctx, const uint32_t* const* left_fk_ptrs, const uint
     bits = (uint32_t)ceil_log2_u64((NR + kTargetBuildRows - 1) / kTargetBuildRows);
     if (bits < 1) bits = 1;
   }
-  unsigned long long counters[4] = {0, 0, 0, 0};
-  for (int attempt = 0; attempt < 3; ++attempt) {
+  unsigned long long counters[5] = {0, 0, 0, 0, 0};
+  bool allow_capacity = true;
+  for (int attempt = 0; attempt < 4; ++attempt) {
     OLAP_TRY(join_once(ctx, left_fk_ptrs, left_y_ptrs, left_rows, n_left_batches, right_pk_ptrs, right_x_ptrs,
-                       right_rows, n_right_batches, in_mem, out_fk, out_y, out_x, out_mem, NL, NR, bits, stats,
-                       counters));
+                       right_rows, n_right_batches, in_mem, out_fk, out_y, out_x, out_mem, NL, NR, bits,
+                       allow_capacity, stats, counters));
+    if (counters[4]) {  // a fixed-capacity region overflowed (skew): redo with exact partitioning
+      allow_capacity = false;
+      continue;
+    }
     if (counters[2] == 0) break;
     bits += 2;  // a build partition overflowed the LDS table: split finer and retry
     if (bits + (uint32_t)ctx->hash_skip_bits > 28) break;
@@ -1000,7 +1118,9 @@ int olap_partition_u32(olap_ctx* ctx, const uint32_t* const* key_ptrs, const uin
   if ((plan.passes >= 2 && !tmp0) || (plan.passes >= 3 && !tmp1) || !fin || (N && (!d_k || !d_p)))
     return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (partition buffers)");
   uint64_t* off = nullptr;
-  OLAP_TRY(partition_side(ctx, cs, payload_ptrs != nullptr, plan, 0u, tmp0, tmp1, fin, &off));
+  SideOut pso;
+  OLAP_TRY(partition_side(ctx, cs, payload_ptrs != nullptr, plan, 0u, tmp0, tmp1, fin, false, nullptr, &pso));
+  off = pso.off;
   if (N) {
     PhaseScope ps(ctx, PH_PART_SCATTER);
     uint64_t grid = (N + 255) / 256;

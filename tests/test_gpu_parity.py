@@ -399,6 +399,63 @@ def test_device_generator_matches_host_mirror(dev):
     assert dev.checksum_rows3_u32(d.ptr, rows.ptr, d.ptr, n) == dg.checksum_rows3(h, np.arange(5, 5 + n, dtype=np.uint32), h)
 
 
+def test_join_capacity_layout_overflow_falls_back_to_exact(dev):
+    """At this size the last radix pass skips its histogram and writes into fixed-capacity
+    regions; a skewed probe side (only 1024 distinct foreign keys) overflows them and the
+    join must transparently redo the partitioning exactly.  Digest must still match."""
+    o = _ops()
+    from dpu_olap_amd import datagen as dg
+    rows, sf = 2 << 20, 64
+    n = sf * rows
+    cols = {k: dev.empty(n, "uint32") for k in ("fk", "y", "pk", "x", "exp")}
+    dev.gen_fk_u32(cols["fk"].ptr, n, dg.SEED, dg.STREAM_FK, 0, n, 1024)  # fk uniform in [0, 1024)
+    dev.gen_uniform_u32(cols["y"].ptr, n, dg.SEED, dg.STREAM_Y, 0)
+    dev.gen_index_u32(cols["pk"].ptr, n, 0)
+    dev.gen_uniform_u32(cols["x"].ptr, n, dg.SEED, dg.STREAM_X, 0)
+    dev.gen_uniform_u32_at(cols["exp"].ptr, cols["fk"].ptr, n, dg.SEED, dg.STREAM_X)
+    expect = dev.checksum_rows3_u32(cols["fk"].ptr, cols["y"].ptr, cols["exp"].ptr, n)
+    batch = lambda c, b: o.DeviceArray(cols[c].ptr + 4 * b * rows, rows, "uint32")
+    j = o.JoinGpu(dev, [(batch("fk", b), batch("y", b)) for b in range(sf)],
+                  [(batch("pk", b), batch("x", b)) for b in range(sf)]).Prepare()
+    out = j.Run()
+    assert out["fk"].rows == n
+    assert dev.checksum_rows3_u32(out["fk"].ptr, out["y"].ptr, out["x"].ptr, n) == expect
+    for c in list(cols.values()) + list(out.values()):
+        dev.release(o.DeviceArray(c.ptr, 0))
+
+
+@pytest.mark.parametrize("capacity_mode", [1, 0])
+def test_join_capacity_and_exact_layouts_agree(dev, capacity_mode):
+    o = _ops()
+    from dpu_olap_amd import datagen as dg
+    rows, sf = 2 << 20, 64
+    n = sf * rows
+    cols = {k: dev.empty(n, "uint32") for k in ("fk", "y", "pk", "x", "exp")}
+    dev.gen_fk_u32(cols["fk"].ptr, n, dg.SEED, dg.STREAM_FK, 0, rows, rows)
+    dev.gen_uniform_u32(cols["y"].ptr, n, dg.SEED, dg.STREAM_Y, 0)
+    dev.gen_index_u32(cols["pk"].ptr, n, 0)
+    dev.gen_uniform_u32(cols["x"].ptr, n, dg.SEED, dg.STREAM_X, 0)
+    dev.gen_uniform_u32_at(cols["exp"].ptr, cols["fk"].ptr, n, dg.SEED, dg.STREAM_X)
+    expect = dev.checksum_rows3_u32(cols["fk"].ptr, cols["y"].ptr, cols["exp"].ptr, n)
+    batch = lambda c, b: o.DeviceArray(cols[c].ptr + 4 * b * rows, rows, "uint32")
+    dev.set_tuning("capacity_mode", capacity_mode)
+    try:
+        j = o.JoinGpu(dev, [(batch("fk", b), batch("y", b)) for b in range(sf)],
+                      [(batch("pk", b), batch("x", b)) for b in range(sf)]).Prepare()
+        out = j.Run()
+        timers = j.Timers()
+    finally:
+        dev.set_tuning("capacity_mode", 1)
+    assert dev.checksum_rows3_u32(out["fk"].ptr, out["y"].ptr, out["x"].ptr, n) == expect
+    # partition-major order survives the capacity layout: partition ids never decrease
+    fk = dev.to_host(out["fk"])
+    part = oracle.wang_hash_np(fk) >> np.uint32(32 - sum(j.stats["radix_bits"]))
+    assert (np.diff(part.astype(np.int64)) >= 0).all()
+    assert "partition-scatter" in timers
+    for c in list(cols.values()) + list(out.values()):
+        dev.release(o.DeviceArray(c.ptr, 0))
+
+
 @pytest.mark.parametrize("sf", [8, 64])
 def test_join_generator_scale_digest(dev, sf):
     """Size-independent property at benchmark shape (SF batches x 2Mi rows per side,
