@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""bench_ops.py -- BM_Filter / BM_Sum / BM_Take equivalents on one MI355X (BASELINE.json
+configs[1..2]); companion of bench.py (which measures the headline BM_Join metric).
+
+Shapes follow the reference's benchmark registrations at scale factor SF (default 2048):
+  BM_Filter {Batches=SF<<7, Batch-Size=64Ki}            host/filter/filter_benchmark.cc:153
+  BM_Sum    {SF, 2Mi} and {SF<<5, 64Ki}                 host/aggr/aggr_benchmark.cc:148-150
+  BM_Take   {SF, 4Mi, 512Ki} and {SF<<6, 64Ki, 8Ki}     host/take/take_benchmark.cc:157-159
+u32 columns (the reference's element type) plus an int64 run of sum and take.  Inputs are
+generated in HBM; items/bytes accounting as in the reference (take counts DATA rows);
+roofline = algorithmic bytes / kernel time / 8 TB/s.  Prints one JSON line
+per benchmark.  Results are verified by order-independent digests / the generator."""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--sf", type=int, default=2048)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--only", default="")
+    ap.add_argument("--cpu", action="store_true", help="also time the oracle / Arrow on a bounded CPU sample")
+    args = ap.parse_args()
+    import numpy as np
+    from dpu_olap_amd import capi
+    from dpu_olap_amd import datagen as dg
+
+    ctx = capi.Context(0)
+    info = ctx.device_info()
+    sf = args.sf
+
+    def timed(fn, phase):
+        for _ in range(args.warmup):
+            fn()
+        ctx.set_profiling(True)
+        ctx.reset_timers()
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            r = fn()
+        ctx.synchronize()
+        wall = (time.perf_counter() - t0) / args.steps
+        tm = ctx.timers()
+        kern = sum(v["ms"] for k, v in tm.items() if k in phase) / args.steps * 1e-3
+        return r, wall, kern, {k: round(v["ms"] / args.steps, 4) for k, v in tm.items()}
+
+    def emit(name, rows, elem, alg_bytes, wall, kern, extra):
+        line = {
+            "metric": name, "value": round(rows / wall / 1e6, 1), "unit": "Mrows/s", "n_gpus": 1,
+            "ms_per_step": round(wall * 1e3, 3), "kernel_ms": round(kern * 1e3, 3),
+            "bytes_processed_GBps": round(rows * elem / wall / 1e9, 1),  # reference accounting: rows x elem size
+            "roofline": {"bound": "hbm", "achieved": round(alg_bytes / kern / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(alg_bytes / kern / 1e9 / HBM_PEAK_GBPS, 4), "algorithmic_bytes": alg_bytes},
+            "sf": sf, "device": info["name"].strip(), "data": "synthetic",
+        }
+        line.update(extra)
+        print(json.dumps(line), flush=True)
+
+    want = lambda n: not args.only or args.only in n
+
+    # ------------------------------------------------------------------ filter
+    if want("filter"):
+        nb, rows = sf << 7, 64 << 10
+        n = nb * rows
+        col = ctx.malloc(n * 4)
+        out = ctx.malloc(n * 4)  # worst case per batch, like the reference's per-DPU output buffer
+        ctx.gen_uniform_u32(col, n, dg.SEED, dg.STREAM_V, 0)
+        outs_l = [out + 4 * b * rows for b in range(nb)]
+        ptrs = capi.ptr_table([col + 4 * b * rows for b in range(nb)])
+        outs = capi.ptr_table(outs_l)
+        rws = capi.u64_table([rows] * nb)
+        (counts, total), wall, kern, tm = timed(lambda: ctx.filter_lt(capi.U32, ptrs, rws, capi.MEM_DEVICE, 1 << 30, outs, capi.MEM_DEVICE),
+                                               ("filter-count", "filter-compact"))
+        # verify a sample of batches against the generator mirror + global count plausibility
+        ok = abs(total / n - 0.25) < 1e-3
+        for b in (0, nb // 2, nb - 1):
+            h = np.empty(counts[b], dtype=np.uint32)
+            ctx.d2h(h.ctypes.data, outs_l[b], h.nbytes)
+            src = dg.uniform_u32(rows, dg.SEED, dg.STREAM_V, b * rows)
+            ok = ok and np.array_equal(h, src[src < (1 << 30)])
+        emit(f"BM_FilterGpu/Batches:{nb}/Batch-Size:{rows}/GPUs:1", n, 4, 4 * n + 4 * total, wall, kern,
+             {"results": total, "selectivity": round(total / n, 5), "verified": bool(ok), "phase_ms": tm,
+              "note": "wall includes the host loop over the batch tables (262144 batches at SF=2048)"})
+        ctx.free(col)
+        ctx.free(out)
+
+    # --------------------------------------------------------------------- sum
+    if want("sum"):
+        for (nb, rows, dt, code, gen) in ((sf, 2 << 20, np.uint32, capi.U32, ctx.gen_uniform_u32),
+                                          (sf << 5, 64 << 10, np.uint32, capi.U32, ctx.gen_uniform_u32),
+                                          (sf, 2 << 20, np.int64, capi.I64, ctx.gen_uniform_u64)):
+            eb = np.dtype(dt).itemsize
+            n = nb * rows
+            col = ctx.malloc(n * eb)
+            gen(col, n, dg.SEED, dg.STREAM_V, 0)
+            ptrs = capi.ptr_table([col + eb * b * rows for b in range(nb)])
+            rws = capi.u64_table([rows] * nb)
+            total, wall, kern, tm = timed(lambda: ctx.sum(code, ptrs, rws, capi.MEM_DEVICE), ("sum",))
+            s, _, _ = ctx.checksum(col, n, eb)  # independent reduction kernel (digest): sum mod 2^64
+            if code == capi.I64 and s >= 1 << 63:
+                s -= 1 << 64
+            emit(f"BM_SumGpu/Batches:{nb}/Batch-Size:{rows}/{np.dtype(dt).name}/GPUs:1", n, eb, eb * n, wall, kern,
+                 {"result": total, "verified": bool(total == s), "phase_ms": tm})
+            ctx.free(col)
+
+    # -------------------------------------------------------------------- take
+    if want("take"):
+        for (nb, rows, m, dt, code) in ((sf, 4 << 20, 512 << 10, np.uint32, capi.U32),
+                                        (sf << 6, 64 << 10, 8 << 10, np.uint32, capi.U32),
+                                        (sf, 4 << 20, 512 << 10, np.int64, capi.I64)):
+            eb = np.dtype(dt).itemsize
+            n, ni = nb * rows, nb * m
+            data, idx, out = ctx.malloc(n * eb), ctx.malloc(ni * 4), ctx.malloc(ni * eb)
+            (ctx.gen_uniform_u32 if eb == 4 else ctx.gen_uniform_u64)(data, n, dg.SEED, dg.STREAM_V, 0)
+            # indices uniform in [0, rows): fk generator with one "left batch" spanning everything
+            ctx.gen_fk_u32(idx, ni, dg.SEED, dg.STREAM_IDX, 0, 1 << 62, rows)
+            ip = [idx + 4 * b * m for b in range(nb)]
+            op = [out + eb * b * m for b in range(nb)]
+            dpt, ipt, opt = capi.ptr_table([data + eb * b * rows for b in range(nb)]), capi.ptr_table(ip), capi.ptr_table(op)
+            drt, irt = capi.u64_table([rows] * nb), capi.u64_table([m] * nb)
+            _, wall, kern, tm = timed(lambda: ctx.take(code, dpt, drt, ipt, irt, capi.MEM_DEVICE, opt, capi.MEM_DEVICE), ("take",))
+            ok = True
+            for b in (0, nb - 1):
+                hi = np.empty(m, dtype=np.uint32)
+                ho = np.empty(m, dtype=dt)
+                ctx.d2h(hi.ctypes.data, ip[b], hi.nbytes)
+                ctx.d2h(ho.ctypes.data, op[b], ho.nbytes)
+                src = (dg.uniform_u32 if eb == 4 else dg.uniform_u64)(rows, dg.SEED, dg.STREAM_V, b * rows)
+                ok = ok and np.array_equal(ho, src[hi].astype(dt) if eb == 4 else src[hi].view(np.int64))
+            emit(f"BM_TakeGpu/Batches:{nb}/Batch-Size:{rows}/Indices-Batch-Size:{m}/{np.dtype(dt).name}/GPUs:1", n, eb,
+                 ni * (4 + 2 * eb), wall, kern, {"indices": ni, "verified": bool(ok), "phase_ms": tm,
+                                                 "note": "items = DATA rows as in take_benchmark.cc:54-56; roofline on 4+2w bytes per index"})
+            for p in (data, idx, out):
+                ctx.free(p)
+
+    # ------------------------------------------------------- CPU side by side
+    if args.cpu:
+        import oracle
+        nb, rows = 256, 64 << 10
+        v = [dg.uniform_u32(rows, dg.SEED, dg.STREAM_V, b * rows) for b in range(nb)]
+        t0 = time.perf_counter()
+        tot = sum(oracle.filter_lt(b, 1 << 30).size for b in v)
+        dt = time.perf_counter() - t0
+        print(json.dumps({"metric": "cpu_baseline filter (oracle, 1 thread)", "value": round(nb * rows / dt / 1e6, 1), "unit": "Mrows/s",
+                          "sample": f"{nb} x 64Ki rows", "results": tot}))
+        t0 = time.perf_counter()
+        tot = sum(oracle.sum_(b) for b in v)
+        dt = time.perf_counter() - t0
+        print(json.dumps({"metric": "cpu_baseline sum (oracle, 1 thread)", "value": round(nb * rows / dt / 1e6, 1), "unit": "Mrows/s",
+                          "sample": f"{nb} x 64Ki rows", "result": tot}))
+        try:
+            import pyarrow as pa
+            import pyarrow.compute as pc
+            arrs = [pa.array(b) for b in v]
+            t0 = time.perf_counter()
+            tot = sum(len(pc.filter(a, pc.less(a, pa.scalar(1 << 30, pa.uint32())))) for a in arrs)
+            dt = time.perf_counter() - t0
+            print(json.dumps({"metric": f"cpu_baseline filter (Arrow {pa.__version__} compute, 1 thread)", "value": round(nb * rows / dt / 1e6, 1),
+                              "unit": "Mrows/s", "sample": f"{nb} x 64Ki rows", "results": tot}))
+        except Exception as e:  # pragma: no cover
+            print(json.dumps({"metric": "cpu_baseline arrow", "error": repr(e)}))
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

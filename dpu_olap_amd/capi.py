@@ -131,13 +131,26 @@ def load_library(path: str | None = None) -> C.CDLL:
 
 
 def _ptr_table(ptrs: Sequence[int]):
+    if isinstance(ptrs, C.Array):  # prebuilt table (hot loops over many batches)
+        return ptrs
     arr = (C.c_void_p * max(len(ptrs), 1))()
     for k, p in enumerate(ptrs):
         arr[k] = p
     return arr
 
 
+def ptr_table(ptrs: Sequence[int]):
+    """Prebuilt host pointer table (ctypes array) for repeated calls."""
+    return _ptr_table(list(ptrs))
+
+
+def u64_table(vals: Iterable[int]):
+    return _u64_table(list(vals))
+
+
 def _u64_table(vals: Iterable[int]):
+    if isinstance(vals, C.Array):
+        return vals
     vals = list(vals)
     arr = (C.c_uint64 * max(len(vals), 1))()
     for k, v in enumerate(vals):
