@@ -68,5 +68,20 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def build_host(jobs: int = 8, verbose: bool = False) -> str:
+    """make -C dpu_olap_amd/host: the C++ Arrow operator classes, the Native (Arrow CPU)
+    operators, the benchmark harness and the operator tests (needs g++ and the Arrow C++
+    libraries bundled with pyarrow)."""
+    host = os.path.join(HERE, "host")
+    r = subprocess.run(["make", "-C", host, f"-j{jobs}"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("C++ host build failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
+    if verbose:
+        print(r.stdout)
+    return os.path.join(host, "build", "olap-query-host")
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    if "--host" in sys.argv:
+        print(build_host(verbose=True))
