@@ -488,3 +488,47 @@ def test_join_generator_scale_digest(dev, sf):
         assert dg.checksum_rows3(ofk, oy, ox) == got
     for c in list(cols.values()) + list(out.values()):
         dev.release(o.DeviceArray(c.ptr, 0))
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_multirank_join_loopback_on_one_gpu(dev, world):
+    """The multi-GPU join's device steps -- owner split (olap_partition_u32 with
+    nr_partitions = G), exchange (emulated by slicing the send regions) and the local join
+    below the owner bits (hash skip bits) -- run for G logical ranks on this one GPU with the
+    product's GpuLocalOps; the union of the shards must digest like the whole join."""
+    import torch
+    from dpu_olap_amd import datagen as dg
+    from dpu_olap_amd.dist_join import GpuLocalOps
+    device = torch.device("cuda", 0)
+    ops = GpuLocalOps(dev, device)
+    rows, nb = 1 << 18, 16          # 16 batches of 256 Ki rows per side, 2 per logical rank at G = 8
+    n = rows * nb
+    col = lambda: torch.empty(n, dtype=torch.int32, device=device)
+    fk, y, pk, x, exp = col(), col(), col(), col(), col()
+    dev.gen_fk_u32(fk.data_ptr(), n, dg.SEED, dg.STREAM_FK, 0, rows, rows)
+    dev.gen_uniform_u32(y.data_ptr(), n, dg.SEED, dg.STREAM_Y, 0)
+    dev.gen_index_u32(pk.data_ptr(), n, 0)
+    dev.gen_uniform_u32(x.data_ptr(), n, dg.SEED, dg.STREAM_X, 0)
+    dev.gen_uniform_u32_at(exp.data_ptr(), fk.data_ptr(), n, dg.SEED, dg.STREAM_X)
+    expect = dev.checksum_rows3_u32(fk.data_ptr(), y.data_ptr(), exp.data_ptr(), n)
+    per = nb // world
+    sends = []
+    for r in range(world):          # every logical rank groups its batches by owner
+        sl = lambda t: [t[(r * per + b) * rows:(r * per + b + 1) * rows] for b in range(per)]
+        lk, lp, loff = ops.partition(sl(fk), sl(y), world)
+        rk, rp, roff = ops.partition(sl(pk), sl(x), world)
+        sends.append((lk, lp, loff, rk, rp, roff))
+    bits = world.bit_length() - 1
+    tot_sum, tot_xor, tot_rows = 0, 0, 0
+    for r in range(world):          # rank r receives region r of every sender
+        cat = lambda i, o: torch.cat([s[i][s[o][r]:s[o][r + 1]] for s in sends])
+        RLk, RLp, RRk, RRp = cat(0, 2), cat(1, 2), cat(3, 5), cat(4, 5)
+        owner = oracle.wang_hash_np(RLk.cpu().numpy().view(np.uint32)) >> np.uint32(32 - bits)
+        assert (owner == r).all()
+        ofk, oy, ox, stats = ops.join([RLk], [RLp], [RRk], [RRp], bits)
+        assert stats["missing_keys"] == 0 and stats["max_build_rows"] <= 6144
+        s, xo = dev.checksum_rows3_u32(ofk.data_ptr(), oy.data_ptr(), ox.data_ptr(), ofk.numel())
+        tot_sum = (tot_sum + s) & ((1 << 64) - 1)
+        tot_xor ^= xo
+        tot_rows += ofk.numel()
+    assert tot_rows == n and (tot_sum, tot_xor) == expect
