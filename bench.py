@@ -216,8 +216,19 @@ def main():
             alg_per_unit = {"partition-scatter": SCATTER_ALG_BYTES_PER_TUPLE, "partition-hist": 6, "join-probe": JOIN_ALG_BYTES_PER_PAIR}
             alg = alg_per_unit.get(dom, 16) * per_launch_units.get(dom, n_local)
             ach = alg / (avg_ms * 1e-3) / 1e9
+            # HBM traffic per launch: PMC counters cannot be read from inside this process; the figure comes
+            # from the committed rocprofv3 PMC passes of this same command (profiles/), only for the config
+            # they were taken on, else null.
+            traffic = None
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic_sf2048.json")))
+                if tj.get("sf") == sf and tj.get("n_gpus") == world and not args.radix_bits >= 0:
+                    traffic = tj["phases"].get(dom)
+            except Exception:
+                traffic = None
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                        "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
+                        "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                        "traffic_source": "profiles/r1_traffic_sf2048.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2)" if traffic else None,
                         "avg_launch_ms": round(avg_ms, 4), "launches": kern[dom]["launches"],
                         "algorithmic_bytes_per_launch": alg}
         whole = JOIN_ALG_BYTES_PER_PAIR * n_total / (dt / args.steps) / 1e9

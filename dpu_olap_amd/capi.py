@@ -28,7 +28,7 @@ EXPORTS = [
     "olap_set_stream", "olap_get_stream", "olap_synchronize", "olap_reserve_workspace",
     "olap_workspace_bytes", "olap_malloc", "olap_free", "olap_memcpy_h2d", "olap_memcpy_d2h",
     "olap_memset", "olap_set_profiling", "olap_reset_timers", "olap_get_timers", "olap_filter_lt",
-    "olap_sum", "olap_take", "olap_partition_u32", "olap_join_u32", "olap_join_configure", "olap_join_set_hash_skip_bits", "olap_set_tuning",
+    "olap_sum", "olap_take", "olap_partition_u32", "olap_partition_tuples_u32", "olap_join_u32", "olap_join_tuples_u32", "olap_join_configure", "olap_join_set_hash_skip_bits", "olap_set_tuning",
     "olap_gen_uniform_u32", "olap_gen_uniform_u64", "olap_gen_index_u32", "olap_gen_fk_u32",
     "olap_gen_uniform_u32_at", "olap_checksum", "olap_checksum_rows3_u32",
 ]
@@ -71,6 +71,26 @@ class JoinStats(C.Structure):
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so
+    (SONAME libamdhip64.so.7, found through torch/lib's RPATH under the name
+    "libamdhip64.so"); libolap_gpu.so asks for "libamdhip64.so.7".  If our library came
+    first the loader would later add torch's copy as a SECOND runtime, which then sees no
+    GPU ("No HIP GPUs are available").  Pre-loading torch's copy makes both resolve to the
+    same object whatever the import order.  Without torch installed nothing happens and the
+    system ROCm runtime is used (as the C++ host binaries do)."""
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass  # fall back to the loader's default resolution
+
+
 def load_library(path: str | None = None) -> C.CDLL:
     """dlopen libolap_gpu.so and declare the prototypes.  Raises if it is missing."""
     global _lib
@@ -82,6 +102,7 @@ def load_library(path: str | None = None) -> C.CDLL:
             f"{p} not found: build the HIP extension first (python -m dpu_olap_amd.build). "
             "There is no CPU fallback for the operator hot path."
         )
+    _share_hip_runtime_with_torch()
     L = C.CDLL(p)
     vp, u64, u32, i = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
     pvp, pu64 = C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)
@@ -110,6 +131,8 @@ def load_library(path: str | None = None) -> C.CDLL:
         "olap_partition_u32": (i, [vp, pvp, pvp, pu64, u64, i, u32, vp, vp, u64, i, pu64]),
         "olap_join_u32": (i, [vp, pvp, pvp, pu64, u64, pvp, pvp, pu64, u64, i, vp, vp, vp, u64, i, pu64,
                               C.POINTER(JoinStats)]),
+        "olap_partition_tuples_u32": (i, [vp, pvp, pvp, pu64, u64, i, u32, vp, u64, pu64]),
+        "olap_join_tuples_u32": (i, [vp, vp, u64, vp, u64, vp, vp, vp, u64, pu64, C.POINTER(JoinStats)]),
         "olap_join_configure": (i, [vp, i, i]),
         "olap_join_set_hash_skip_bits": (i, [vp, i]),
         "olap_set_tuning": (i, [vp, C.c_char_p, i]),
@@ -277,6 +300,22 @@ class Context:
         self._check(self.lib.olap_partition_u32(self.h, _ptr_table(key_ptrs), pay, _u64_table(rows), len(key_ptrs), in_mem,
                                                 nr_partitions, out_keys, out_payload, out_capacity, out_mem, offs))
         return [offs[k] for k in range(nr_partitions + 1)]
+
+    def partition_tuples_u32(self, key_ptrs, payload_ptrs, rows, in_mem: int, nr_partitions: int, out_tuples: int,
+                             out_capacity: int):
+        offs = (C.c_uint64 * (nr_partitions + 1))()
+        pay = _ptr_table(payload_ptrs) if payload_ptrs is not None else None
+        self._check(self.lib.olap_partition_tuples_u32(self.h, _ptr_table(key_ptrs), pay, _u64_table(rows), len(key_ptrs),
+                                                       in_mem, nr_partitions, out_tuples, out_capacity, offs))
+        return [offs[k] for k in range(nr_partitions + 1)]
+
+    def join_tuples_u32(self, left_tuples: int, n_left: int, right_tuples: int, n_right: int, out_fk: int, out_y: int,
+                        out_x: int, out_capacity: int):
+        n = C.c_uint64()
+        st = JoinStats()
+        self._check(self.lib.olap_join_tuples_u32(self.h, left_tuples, n_left, right_tuples, n_right, out_fk, out_y,
+                                                  out_x, out_capacity, C.byref(n), C.byref(st)))
+        return n.value, st.as_dict()
 
     def join_configure(self, radix_bits_total: int = -1, max_bits_per_pass: int = 0):
         self._check(self.lib.olap_join_configure(self.h, radix_bits_total, max_bits_per_pass))

@@ -87,20 +87,37 @@ __device__ __forceinline__ TileRange block_tiles(const PassSrc& s) {
   return r;
 }
 
+// Batch-table entries of the batch the workgroup is currently reading: consecutive tiles
+// mostly stay in one batch (a 2 Mi-row batch is 256 tiles), so the dependent loads
+// "pointer table -> data" are paid once per batch instead of once per tile.
+struct ColsCursor {
+  uint32_t batch = 0xFFFFFFFFu;
+  const uint32_t* kp = nullptr;
+  const uint32_t* pp = nullptr;
+  uint64_t rows = 0, row0 = 0;
+};
+
 // Loads one tile: kPTile / BLOCK tuples per thread, valid bits in the returned mask.
 template <int SRC, int BLOCK, bool WANT_PAYLOAD>
-__device__ __forceinline__ uint32_t load_tile(const PassSrc& s, const TileRange& r, uint64_t tile,
+__device__ __forceinline__ uint32_t load_tile(const PassSrc& s, const TileRange& r, uint64_t tile, ColsCursor& cur,
                                               uint32_t (&key)[kPTile / BLOCK], uint32_t (&pay)[kPTile / BLOCK]) {
   constexpr int TPT = kPTile / BLOCK;
   uint32_t mask = 0;
   if (SRC == SRC_COLS) {
     const Loc l = locate(s.v, tile);
-    const uint64_t rows = batch_rows(s.v, l.batch);
+    if (l.batch != cur.batch) {  // workgroup-uniform
+      cur.batch = l.batch;
+      cur.kp = (const uint32_t*)s.key_ptrs[l.batch];
+      cur.pp = s.pay_ptrs ? (const uint32_t*)s.pay_ptrs[l.batch] : nullptr;
+      cur.rows = batch_rows(s.v, l.batch);
+      cur.row0 = batch_row0(s.v, l.batch);
+    }
+    const uint64_t rows = cur.rows;
     const uint64_t r0 = l.local_unit * kPTile;
     const uint32_t n = (uint32_t)min((uint64_t)kPTile, rows - r0);
-    const uint32_t* kp = (const uint32_t*)s.key_ptrs[l.batch] + r0;
-    const uint32_t* pp = s.pay_ptrs ? (const uint32_t*)s.pay_ptrs[l.batch] + r0 : nullptr;
-    const uint32_t rowid0 = (uint32_t)(batch_row0(s.v, l.batch) + r0);
+    const uint32_t* kp = cur.kp + r0;
+    const uint32_t* pp = cur.pp ? cur.pp + r0 : nullptr;
+    const uint32_t rowid0 = (uint32_t)(cur.row0 + r0);
     const bool fast = n == kPTile && ((((uintptr_t)kp) | ((uintptr_t)pp)) & 15) == 0;
     if (fast) {
       uint4 kv[TPT / 4], pv[TPT / 4];
@@ -163,7 +180,13 @@ __device__ __forceinline__ uint32_t load_tile(const PassSrc& s, const TileRange&
     for (int j = 0; j < TPT / 2; ++j) {
       const uint64_t i0 = base + (uint64_t)(j * BLOCK + threadIdx.x) * 2;
       uint4 t = make_uint4(0, 0, 0, 0);
-      if (i0 < r.hi) t = *(const uint4*)(s.tuples + i0);  // array is padded by 2 tuples
+      if (i0 + 1 < r.hi) {
+        t = *(const uint4*)(s.tuples + i0);
+      } else if (i0 < r.hi) {  // last, odd tuple: never read past the end of a caller's array
+        const uint2 t1 = s.tuples[i0];
+        t.x = t1.x;
+        t.y = t1.y;
+      }
       key[2 * j] = t.x;
       pay[2 * j] = t.y;
       key[2 * j + 1] = t.z;
@@ -185,9 +208,10 @@ __global__ __launch_bounds__(BLOCK) void k_part_hist(PassSrc s, uint32_t shift, 
   for (uint32_t b = threadIdx.x; b < F; b += BLOCK) cl[b] = 0;
   __syncthreads();
   const TileRange r = block_tiles<SRC>(s);
+  ColsCursor cur;
   for (uint64_t tile = r.t0; tile < r.t1; ++tile) {
     uint32_t key[TPT], pay[TPT];
-    const uint32_t mask = load_tile<SRC, BLOCK, false>(s, r, tile, key, pay);
+    const uint32_t mask = load_tile<SRC, BLOCK, false>(s, r, tile, cur, key, pay);
 #pragma unroll
     for (int i = 0; i < TPT; ++i) {
       if (mask & (1u << i)) atomicAdd(&cl[(wang_hash(key[i]) >> shift) & (F - 1)], 1u);
@@ -265,9 +289,10 @@ __global__ __launch_bounds__(kPBlock, 4) void k_part_scatter(PassSrc s, uint32_t
   __syncthreads();
   const unsigned lane = lane_id();
   const unsigned wave = threadIdx.x / kWave;
+  ColsCursor cur;
   for (uint64_t tile = r.t0; tile < r.t1; ++tile) {
     uint32_t key[kTPT], pay[kTPT], br[kTPT];
-    const uint32_t mask = load_tile<SRC, kPBlock, true>(s, r, tile, key, pay);
+    const uint32_t mask = load_tile<SRC, kPBlock, true>(s, r, tile, cur, key, pay);
     // (2) bucket + rank inside the bucket
 #pragma unroll
     for (int i = 0; i < kTPT; ++i) {
@@ -408,7 +433,8 @@ __global__ __launch_bounds__(kWBlock) void k_part_scatter_wc(PassSrc s, uint32_t
   __syncthreads();
   uint32_t key[kWTPT], pay[kWTPT], nkey[kWTPT], npay[kWTPT];
   uint32_t mask = 0, nmask = 0;
-  if (r.t0 < r.t1) mask = load_tile<SRC, kWBlock, true>(s, r, r.t0, key, pay);
+  ColsCursor cur;
+  if (r.t0 < r.t1) mask = load_tile<SRC, kWBlock, true>(s, r, r.t0, cur, key, pay);
   for (uint64_t tile = r.t0; tile < r.t1; ++tile) {
     // (2) bucket + rank of every tuple
     uint32_t br[kWTPT];
@@ -467,7 +493,7 @@ __global__ __launch_bounds__(kWBlock) void k_part_scatter_wc(PassSrc s, uint32_t
     }
     // next tile's loads fly during the copy-out
     nmask = 0;
-    if (tile + 1 < r.t1) nmask = load_tile<SRC, kWBlock, true>(s, r, tile + 1, nkey, npay);
+    if (tile + 1 < r.t1) nmask = load_tile<SRC, kWBlock, true>(s, r, tile + 1, cur, nkey, npay);
     __syncthreads();
     // (5) copy-out: 4 consecutive lanes write one aligned 64-byte line, 16 B (2 tuples) each
 #pragma unroll 1
@@ -792,17 +818,30 @@ static bool capacity_eligible(const olap_ctx* ctx, uint64_t rows, const PassPlan
   return n_seg_last >= (uint64_t)ctx->compute_units && rows / P >= 512;
 }
 
-static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, const PassPlan& plan,
-                          uint32_t skip_bits, uint2* tmp0, uint2* tmp1, uint2* final_tuples,
-                          bool capm, unsigned long long* d_overflow, SideOut* so) {
-  const uint64_t rows = cs.view.total_rows;
+// Input of pass 0: the batched columns `cs`, or (tuple_in != nullptr) an array of tuple_n
+// (key, payload) tuples already in HBM -- what a rank receives from the all-to-all.
+static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, const uint2* tuple_in,
+                          uint64_t tuple_n, const PassPlan& plan, uint32_t skip_bits, uint2* tmp0, uint2* tmp1,
+                          uint2* final_tuples, bool capm, unsigned long long* d_overflow, SideOut* so) {
+  const uint64_t rows = tuple_in ? tuple_n : cs.view.total_rows;
   PassSrc src{};
-  src.v = cs.view;
-  src.key_ptrs = cs.dev_ptr_tables[0];
-  src.pay_ptrs = has_payload ? cs.dev_ptr_tables[1] : nullptr;
   uint64_t n_seg = 1;
   const uint64_t* seg_in = nullptr;
   const uint2* in_tuples = nullptr;
+  if (tuple_in) {
+    uint64_t* seg0 = (uint64_t*)ws_alloc(ctx, 16);
+    uint64_t* h_seg0 = (uint64_t*)pinned_alloc(ctx, 16);
+    if (!seg0 || !h_seg0) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (segment table)");
+    h_seg0[0] = 0;
+    h_seg0[1] = tuple_n;
+    OLAP_HIP(ctx, hipMemcpyAsync(seg0, h_seg0, 16, hipMemcpyHostToDevice, ctx->stream));
+    seg_in = seg0;
+    in_tuples = tuple_in;
+  } else {
+    src.v = cs.view;
+    src.key_ptrs = cs.dev_ptr_tables[0];
+    src.pay_ptrs = has_payload ? cs.dev_ptr_tables[1] : nullptr;
+  }
   uint32_t consumed = skip_bits;
   OLAP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_scatter<SRC_COLS>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, kScatterLds));
@@ -822,7 +861,8 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
     const uint32_t shift = 32 - consumed;
     uint2* out = (i == plan.passes - 1) ? final_tuples : ((i & 1) ? tmp1 : tmp0);
     uint64_t blocks, bseg;
-    if (i == 0) {
+    const bool cols = i == 0 && !tuple_in;
+    if (cols) {
       const uint64_t tiles = cs.view.total_units;
       uint64_t nb = (uint64_t)ctx->compute_units * (wc ? 1 : 2);
       if (nb > tiles) nb = tiles;
@@ -858,7 +898,7 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
     if (!hist || !seg_out) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (partition pass %d)", i);
     {
       PhaseScope ps(ctx, PH_PART_HIST);
-      if (i == 0)
+      if (cols)
         hipLaunchKernelGGL((k_part_hist<SRC_COLS, kWBlock>), dim3((unsigned)blocks), dim3(kWBlock), 0, ctx->stream, src, shift, fbits, hist);
       else
         hipLaunchKernelGGL((k_part_hist<SRC_TUPLES, kWBlock>), dim3((unsigned)blocks), dim3(kWBlock), 0, ctx->stream, src, shift, fbits, hist);
@@ -872,13 +912,13 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
     }
     {
       PhaseScope ps(ctx, PH_PART_SCATTER);
-      if (wc && i == 0)
+      if (wc && cols)
         hipLaunchKernelGGL((k_part_scatter_wc<SRC_COLS, false>), dim3((unsigned)blocks), dim3(kWBlock), kWcLds, ctx->stream,
                            src, shift, fbits, (const uint32_t*)hist, (const uint64_t*)seg_out, out, CapOut{});
       else if (wc)
         hipLaunchKernelGGL((k_part_scatter_wc<SRC_TUPLES, false>), dim3((unsigned)blocks), dim3(kWBlock), kWcLds, ctx->stream,
                            src, shift, fbits, (const uint32_t*)hist, (const uint64_t*)seg_out, out, CapOut{});
-      else if (i == 0)
+      else if (cols)
         hipLaunchKernelGGL((k_part_scatter<SRC_COLS>), dim3((unsigned)blocks), dim3(kPBlock), kScatterLds, ctx->stream,
                            src, shift, fbits, (const uint32_t*)hist, (const uint64_t*)seg_out, out);
       else
@@ -903,11 +943,32 @@ static int check_side(olap_ctx* ctx, const void* keys, const uint64_t* rows, uin
   return OLAP_OK;
 }
 
-static int join_once(olap_ctx* ctx, const uint32_t* const* lfk, const uint32_t* const* ly, const uint64_t* lrows,
-                     uint64_t lnb, const uint32_t* const* rpk, const uint32_t* const* rx, const uint64_t* rrows,
-                     uint64_t rnb, int in_mem, uint32_t* out_fk, uint32_t* out_y, uint32_t* out_x, int out_mem,
+// Join inputs: batched columns per side, or (device only) pre-zipped tuple arrays.
+struct JoinIn {
+  const uint32_t* const* lfk = nullptr;
+  const uint32_t* const* ly = nullptr;
+  const uint64_t* lrows = nullptr;
+  uint64_t lnb = 0;
+  const uint32_t* const* rpk = nullptr;
+  const uint32_t* const* rx = nullptr;
+  const uint64_t* rrows = nullptr;
+  uint64_t rnb = 0;
+  int in_mem = OLAP_MEM_DEVICE;
+  const uint2* l_tuples = nullptr;
+  const uint2* r_tuples = nullptr;
+};
+
+static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t* out_y, uint32_t* out_x, int out_mem,
                      uint64_t NL, uint64_t NR, uint32_t total_bits, bool allow_capacity, olap_join_stats* st,
                      unsigned long long counters[5]) {
+  const uint32_t* const* lfk = in.lfk;
+  const uint32_t* const* ly = in.ly;
+  const uint32_t* const* rpk = in.rpk;
+  const uint32_t* const* rx = in.rx;
+  const uint64_t* lrows = in.lrows;
+  const uint64_t* rrows = in.rrows;
+  const uint64_t lnb = in.l_tuples ? 0 : in.lnb, rnb = in.r_tuples ? 0 : in.rnb;
+  const int in_mem = in.in_mem;
   PassPlan plan;
   OLAP_TRY(make_plan(ctx, total_bits, &plan));
   if (plan.total_bits + (uint32_t)ctx->hash_skip_bits > 32)
@@ -930,8 +991,8 @@ static int join_once(olap_ctx* ctx, const uint32_t* const* lfk, const uint32_t* 
   OLAP_TRY(pinned_begin(ctx, (lnb + rnb + 2) * 8 * 8 + 8192));
   OLAP_TRY(ws_begin(ctx, need));
   ColumnSet lcs, rcs;
-  OLAP_TRY(build_column_set(ctx, lcols, 2, eb, lrows, lnb, in_mem, kPTile, &lcs));
-  OLAP_TRY(build_column_set(ctx, rcols, 2, eb, rrows, rnb, in_mem, kPTile, &rcs));
+  if (!in.l_tuples) OLAP_TRY(build_column_set(ctx, lcols, 2, eb, lrows, lnb, in_mem, kPTile, &lcs));
+  if (!in.r_tuples) OLAP_TRY(build_column_set(ctx, rcols, 2, eb, rrows, rnb, in_mem, kPTile, &rcs));
   uint2* tmp0 = plan.passes >= 2 ? (uint2*)ws_alloc(ctx, (maxN + 2) * 8) : nullptr;
   uint2* tmp1 = plan.passes >= 3 ? (uint2*)ws_alloc(ctx, (maxN + 2) * 8) : nullptr;
   uint2* Lt = (uint2*)ws_alloc(ctx, (lt_tuples + 2) * 8);
@@ -947,8 +1008,10 @@ static int join_once(olap_ctx* ctx, const uint32_t* const* lfk, const uint32_t* 
     return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (join buffers)");
   OLAP_HIP(ctx, hipMemsetAsync(d_cnt, 0, 40, ctx->stream));
   SideOut lso, rso;
-  OLAP_TRY(partition_side(ctx, lcs, true, plan, (uint32_t)ctx->hash_skip_bits, tmp0, tmp1, Lt, lcap, d_cnt + 4, &lso));
-  OLAP_TRY(partition_side(ctx, rcs, true, plan, (uint32_t)ctx->hash_skip_bits, tmp0, tmp1, Rt, rcap, d_cnt + 4, &rso));
+  OLAP_TRY(partition_side(ctx, lcs, true, in.l_tuples, NL, plan, (uint32_t)ctx->hash_skip_bits, tmp0, tmp1, Lt, lcap,
+                          d_cnt + 4, &lso));
+  OLAP_TRY(partition_side(ctx, rcs, true, in.r_tuples, NR, plan, (uint32_t)ctx->hash_skip_bits, tmp0, tmp1, Rt, rcap,
+                          d_cnt + 4, &rso));
   {
     PhaseScope ps(ctx, PH_JOIN_PROBE);
     uint64_t grid = (uint64_t)ctx->compute_units * 8;
@@ -980,6 +1043,46 @@ static int join_once(olap_ctx* ctx, const uint32_t* const* lfk, const uint32_t* 
     st->missing_keys = counters[0];
   }
   return resolve_timers(ctx);
+}
+
+static int join_run(olap_ctx* ctx, const JoinIn& jin, uint64_t NL, uint64_t NR, uint32_t* out_fk, uint32_t* out_y,
+                    uint32_t* out_x, uint64_t out_capacity, int out_mem, uint64_t* out_rows, olap_join_stats* stats) {
+  if (stats) std::memset(stats, 0, sizeof *stats);
+  *out_rows = 0;
+  if (NL == 0) return OLAP_OK;
+  if (NL > out_capacity) return ctx->fail(OLAP_ERR_CAPACITY, "output capacity %llu < %llu left rows",
+                                          (unsigned long long)out_capacity, (unsigned long long)NL);
+  if (!out_fk || !out_y || !out_x) return ctx->fail(OLAP_ERR_INVALID, "null output column");
+  if (NR == 0) {
+    if (stats) { stats->left_rows = NL; stats->missing_keys = NL; }
+    return ctx->fail(OLAP_ERR_NO_MATCH, "right table is empty: %llu foreign keys without a match", (unsigned long long)NL);
+  }
+  uint32_t bits;
+  if (ctx->radix_bits_total >= 0) {
+    bits = ctx->radix_bits_total < 1 ? 1u : (uint32_t)ctx->radix_bits_total;
+  } else {
+    bits = (uint32_t)ceil_log2_u64((NR + kTargetBuildRows - 1) / kTargetBuildRows);
+    if (bits < 1) bits = 1;
+  }
+  unsigned long long counters[5] = {0, 0, 0, 0, 0};
+  bool allow_capacity = true;
+  for (int attempt = 0; attempt < 4; ++attempt) {
+    OLAP_TRY(join_once(ctx, jin, out_fk, out_y, out_x, out_mem, NL, NR, bits, allow_capacity, stats, counters));
+    if (counters[4]) {  // a fixed-capacity region overflowed (skew): redo with exact partitioning
+      allow_capacity = false;
+      continue;
+    }
+    if (counters[2] == 0) break;
+    bits += 2;  // a build partition overflowed the LDS table: split finer and retry
+    if (bits + (uint32_t)ctx->hash_skip_bits > 28) break;
+  }
+  if (counters[2])
+    return ctx->fail(OLAP_ERR_OVERFLOW, "%llu partition(s) exceed the LDS hash table (%u rows); largest build partition %llu rows",
+                     counters[2], kTableCap, counters[3]);
+  if (counters[0])
+    return ctx->fail(OLAP_ERR_NO_MATCH, "%llu foreign key(s) without a matching primary key", counters[0]);
+  *out_rows = NL;
+  return OLAP_OK;
 }
 
 }  // namespace olap
@@ -1037,50 +1140,41 @@ int olap_join_u32(olap_ctx* ctx, const uint32_t* const* left_fk_ptrs, const uint
   OLAP_TRY(check_side(ctx, right_pk_ptrs, right_rows, n_right_batches, &NR));
   if ((n_left_batches && !left_y_ptrs) || (n_right_batches && !right_x_ptrs))
     return ctx->fail(OLAP_ERR_INVALID, "null payload table");
-  if (stats) std::memset(stats, 0, sizeof *stats);
-  *out_rows = 0;
-  if (NL == 0) return OLAP_OK;
-  if (NL > out_capacity) return ctx->fail(OLAP_ERR_CAPACITY, "output capacity %llu < %llu left rows",
-                                          (unsigned long long)out_capacity, (unsigned long long)NL);
-  if (!out_fk || !out_y || !out_x) return ctx->fail(OLAP_ERR_INVALID, "null output column");
-  if (NR == 0) {
-    if (stats) { stats->left_rows = NL; stats->missing_keys = NL; }
-    return ctx->fail(OLAP_ERR_NO_MATCH, "right table is empty: %llu foreign keys without a match", (unsigned long long)NL);
-  }
-  uint32_t bits;
-  if (ctx->radix_bits_total >= 0) {
-    bits = ctx->radix_bits_total < 1 ? 1u : (uint32_t)ctx->radix_bits_total;
-  } else {
-    bits = (uint32_t)ceil_log2_u64((NR + kTargetBuildRows - 1) / kTargetBuildRows);
-    if (bits < 1) bits = 1;
-  }
-  unsigned long long counters[5] = {0, 0, 0, 0, 0};
-  bool allow_capacity = true;
-  for (int attempt = 0; attempt < 4; ++attempt) {
-    OLAP_TRY(join_once(ctx, left_fk_ptrs, left_y_ptrs, left_rows, n_left_batches, right_pk_ptrs, right_x_ptrs,
-                       right_rows, n_right_batches, in_mem, out_fk, out_y, out_x, out_mem, NL, NR, bits,
-                       allow_capacity, stats, counters));
-    if (counters[4]) {  // a fixed-capacity region overflowed (skew): redo with exact partitioning
-      allow_capacity = false;
-      continue;
-    }
-    if (counters[2] == 0) break;
-    bits += 2;  // a build partition overflowed the LDS table: split finer and retry
-    if (bits + (uint32_t)ctx->hash_skip_bits > 28) break;
-  }
-  if (counters[2])
-    return ctx->fail(OLAP_ERR_OVERFLOW, "%llu partition(s) exceed the LDS hash table (%u rows); largest build partition %llu rows",
-                     counters[2], kTableCap, counters[3]);
-  if (counters[0])
-    return ctx->fail(OLAP_ERR_NO_MATCH, "%llu foreign key(s) without a matching primary key", counters[0]);
-  *out_rows = NL;
-  return OLAP_OK;
+  JoinIn jin;
+  jin.lfk = left_fk_ptrs;
+  jin.ly = left_y_ptrs;
+  jin.lrows = left_rows;
+  jin.lnb = n_left_batches;
+  jin.rpk = right_pk_ptrs;
+  jin.rx = right_x_ptrs;
+  jin.rrows = right_rows;
+  jin.rnb = n_right_batches;
+  jin.in_mem = in_mem;
+  return join_run(ctx, jin, NL, NR, out_fk, out_y, out_x, out_capacity, out_mem, out_rows, stats);
 }
 
-int olap_partition_u32(olap_ctx* ctx, const uint32_t* const* key_ptrs, const uint32_t* const* payload_ptrs,
-                       const uint64_t* rows, uint64_t n_batches, int in_mem, uint32_t nr_partitions,
-                       uint32_t* out_keys, uint32_t* out_payload, uint64_t out_capacity, int out_mem,
-                       uint64_t* out_offsets) {
+int olap_join_tuples_u32(olap_ctx* ctx, const uint64_t* left_tuples, uint64_t n_left, const uint64_t* right_tuples,
+                         uint64_t n_right, uint32_t* out_fk, uint32_t* out_y, uint32_t* out_x, uint64_t out_capacity,
+                         uint64_t* out_rows, olap_join_stats* stats) {
+  if (!ctx) return OLAP_ERR_INVALID;
+  if (hipSetDevice(ctx->device) != hipSuccess) return ctx->fail(OLAP_ERR_DEVICE, "hipSetDevice failed");
+  if (!out_rows) return ctx->fail(OLAP_ERR_INVALID, "out_rows is null");
+  if ((n_left && !left_tuples) || (n_right && !right_tuples)) return ctx->fail(OLAP_ERR_INVALID, "null tuple array");
+  if ((((uintptr_t)left_tuples) | ((uintptr_t)right_tuples)) & 15)
+    return ctx->fail(OLAP_ERR_INVALID, "tuple arrays must be 16-byte aligned");
+  if (n_left > (1ull << 32) || n_right > (1ull << 32)) return ctx->fail(OLAP_ERR_INVALID, "more than 2^32 rows on one side");
+  JoinIn jin;
+  jin.l_tuples = reinterpret_cast<const uint2*>(left_tuples);
+  jin.r_tuples = reinterpret_cast<const uint2*>(right_tuples);
+  return join_run(ctx, jin, n_left, n_right, out_fk, out_y, out_x, out_capacity, OLAP_MEM_DEVICE, out_rows, stats);
+}
+
+// Shared body of olap_partition_u32 (keys/payload columns out) and
+// olap_partition_tuples_u32 (zipped tuples straight into the caller's device buffer).
+static int partition_run(olap_ctx* ctx, const uint32_t* const* key_ptrs, const uint32_t* const* payload_ptrs,
+                         const uint64_t* rows, uint64_t n_batches, int in_mem, uint32_t nr_partitions,
+                         uint32_t* out_keys, uint32_t* out_payload, uint2* out_tuples, uint64_t out_capacity,
+                         int out_mem, uint64_t* out_offsets) {
   if (!ctx) return OLAP_ERR_INVALID;
   if (hipSetDevice(ctx->device) != hipSuccess) return ctx->fail(OLAP_ERR_DEVICE, "hipSetDevice failed");
   if ((in_mem != OLAP_MEM_HOST && in_mem != OLAP_MEM_DEVICE) || (out_mem != OLAP_MEM_HOST && out_mem != OLAP_MEM_DEVICE))
@@ -1092,11 +1186,11 @@ int olap_partition_u32(olap_ctx* ctx, const uint32_t* const* key_ptrs, const uin
   uint64_t N = 0;
   OLAP_TRY(check_side(ctx, key_ptrs, rows, n_batches, &N));
   if (N > out_capacity) return ctx->fail(OLAP_ERR_CAPACITY, "output capacity too small");
-  if (N && (!out_keys || !out_payload)) return ctx->fail(OLAP_ERR_INVALID, "null output column");
+  const bool zipped = out_tuples != nullptr;
+  if (N && !zipped && (!out_keys || !out_payload)) return ctx->fail(OLAP_ERR_INVALID, "null output column");
+  if (zipped && (((uintptr_t)out_tuples) & 15)) return ctx->fail(OLAP_ERR_INVALID, "out_tuples must be 16-byte aligned");
   PassPlan plan;
-  const int saved = ctx->max_bits_per_pass;
   OLAP_TRY(make_plan(ctx, (uint32_t)ceil_log2_u64(nr_partitions), &plan));
-  (void)saved;
   const uint32_t eb[2] = {4, 4};
   const int ncols = payload_ptrs ? 2 : 1;
   const void* const* cols[2] = {(const void* const*)key_ptrs, (const void* const*)payload_ptrs};
@@ -1109,19 +1203,18 @@ int olap_partition_u32(olap_ctx* ctx, const uint32_t* const* key_ptrs, const uin
   OLAP_TRY(build_column_set(ctx, cols, ncols, eb, rows, n_batches, in_mem, kPTile, &cs));
   uint2* tmp0 = plan.passes >= 2 ? (uint2*)ws_alloc(ctx, (N + 2) * 8) : nullptr;
   uint2* tmp1 = plan.passes >= 3 ? (uint2*)ws_alloc(ctx, (N + 2) * 8) : nullptr;
-  uint2* fin = (uint2*)ws_alloc(ctx, (N + 2) * 8);
+  uint2* fin = zipped ? out_tuples : (uint2*)ws_alloc(ctx, (N + 2) * 8);
   uint32_t *d_k = out_keys, *d_p = out_payload;
-  if (out_mem == OLAP_MEM_HOST) {
+  if (!zipped && out_mem == OLAP_MEM_HOST) {
     d_k = (uint32_t*)ws_alloc(ctx, N * 4 + 4);
     d_p = (uint32_t*)ws_alloc(ctx, N * 4 + 4);
   }
-  if ((plan.passes >= 2 && !tmp0) || (plan.passes >= 3 && !tmp1) || !fin || (N && (!d_k || !d_p)))
+  if ((plan.passes >= 2 && !tmp0) || (plan.passes >= 3 && !tmp1) || (N && !fin) || (N && !zipped && (!d_k || !d_p)))
     return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (partition buffers)");
-  uint64_t* off = nullptr;
   SideOut pso;
-  OLAP_TRY(partition_side(ctx, cs, payload_ptrs != nullptr, plan, 0u, tmp0, tmp1, fin, false, nullptr, &pso));
-  off = pso.off;
-  if (N) {
+  OLAP_TRY(partition_side(ctx, cs, payload_ptrs != nullptr, nullptr, 0, plan, (uint32_t)ctx->hash_skip_bits, tmp0, tmp1,
+                          fin, false, nullptr, &pso));
+  if (N && !zipped) {
     PhaseScope ps(ctx, PH_PART_SCATTER);
     uint64_t grid = (N + 255) / 256;
     const uint64_t cap = (uint64_t)ctx->compute_units * 16;
@@ -1129,14 +1222,36 @@ int olap_partition_u32(olap_ctx* ctx, const uint32_t* const* key_ptrs, const uin
     hipLaunchKernelGGL(k_unzip, dim3((unsigned)grid), dim3(256), 0, ctx->stream, (const uint2*)fin, N, d_k, d_p);
     OLAP_HIP(ctx, hipGetLastError());
   }
-  OLAP_HIP(ctx, hipMemcpyAsync(out_offsets, off, ((uint64_t)nr_partitions + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
-  if (out_mem == OLAP_MEM_HOST && N) {
+  OLAP_HIP(ctx, hipMemcpyAsync(out_offsets, pso.off, ((uint64_t)nr_partitions + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (!zipped && out_mem == OLAP_MEM_HOST && N) {
     PhaseScope ps(ctx, PH_COPY_FROM);
     OLAP_HIP(ctx, hipMemcpyAsync(out_keys, d_k, N * 4, hipMemcpyDeviceToHost, ctx->stream));
     OLAP_HIP(ctx, hipMemcpyAsync(out_payload, d_p, N * 4, hipMemcpyDeviceToHost, ctx->stream));
   }
   OLAP_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return resolve_timers(ctx);
+}
+
+int olap_partition_u32(olap_ctx* ctx, const uint32_t* const* key_ptrs, const uint32_t* const* payload_ptrs,
+                       const uint64_t* rows, uint64_t n_batches, int in_mem, uint32_t nr_partitions,
+                       uint32_t* out_keys, uint32_t* out_payload, uint64_t out_capacity, int out_mem,
+                       uint64_t* out_offsets) {
+  return partition_run(ctx, key_ptrs, payload_ptrs, rows, n_batches, in_mem, nr_partitions, out_keys, out_payload,
+                       nullptr, out_capacity, out_mem, out_offsets);
+}
+
+int olap_partition_tuples_u32(olap_ctx* ctx, const uint32_t* const* key_ptrs, const uint32_t* const* payload_ptrs,
+                              const uint64_t* rows, uint64_t n_batches, int in_mem, uint32_t nr_partitions,
+                              uint64_t* out_tuples, uint64_t out_capacity, uint64_t* out_offsets) {
+  if (ctx && !out_tuples) {
+    uint64_t n = 0;
+    for (uint64_t b = 0; rows && b < n_batches; ++b) n += rows[b];
+    if (n) return ctx->fail(OLAP_ERR_INVALID, "out_tuples is null");
+    static uint64_t dummy[2] __attribute__((aligned(16)));
+    out_tuples = dummy;  // nothing is written for an empty input
+  }
+  return partition_run(ctx, key_ptrs, payload_ptrs, rows, n_batches, in_mem, nr_partitions, nullptr, nullptr,
+                       reinterpret_cast<uint2*>(out_tuples), out_capacity, OLAP_MEM_DEVICE, out_offsets);
 }
 
 }  // extern "C"

@@ -50,17 +50,42 @@ class GpuLocalOps:
         rows = [int(k.numel()) for k in keys]
         n = sum(rows)
         ok, op = self.empty(n), self.empty(n)
-        torch.cuda.synchronize(self.device)
+        torch.cuda.current_stream(self.device).synchronize()  # inputs come from torch's stream; do not wait for RCCL's
         offs = self.ctx.partition_u32([k.data_ptr() for k in keys], [p.data_ptr() for p in payload], rows,
                                       capi.MEM_DEVICE, nr_partitions, ok.data_ptr(), op.data_ptr(), n, capi.MEM_DEVICE)
         return ok, op, offs
+
+    def empty_tuples(self, n: int) -> torch.Tensor:
+        return torch.empty(max(n, 2), dtype=torch.int64, device=self.device)[:n]
+
+    def partition_tuples(self, keys: Sequence[torch.Tensor], payload: Sequence[torch.Tensor], nr_partitions: int):
+        """Owner split that keeps (key, payload) zipped: int64 tensor key | payload << 32."""
+        rows = [int(k.numel()) for k in keys]
+        n = sum(rows)
+        out = self.empty_tuples(n)
+        torch.cuda.current_stream(self.device).synchronize()  # inputs come from torch's stream; do not wait for RCCL's
+        offs = self.ctx.partition_tuples_u32([k.data_ptr() for k in keys], [p.data_ptr() for p in payload], rows,
+                                             capi.MEM_DEVICE, nr_partitions, out.data_ptr(), n)
+        return out, offs
+
+    def join_tuples(self, lt: torch.Tensor, rt: torch.Tensor, skip_bits: int = 0):
+        n = int(lt.numel())
+        out = [self.empty(n) for _ in range(3)]
+        torch.cuda.current_stream(self.device).synchronize()  # inputs come from torch's stream; do not wait for RCCL's
+        self.ctx.join_set_hash_skip_bits(skip_bits)
+        try:
+            got, stats = self.ctx.join_tuples_u32(lt.data_ptr(), n, rt.data_ptr(), int(rt.numel()), out[0].data_ptr(),
+                                                  out[1].data_ptr(), out[2].data_ptr(), n)
+        finally:
+            self.ctx.join_set_hash_skip_bits(0)
+        return out[0][:got], out[1][:got], out[2][:got], stats
 
     def join(self, lfk, ly, rpk, rx, skip_bits: int = 0):
         lrows = [int(t.numel()) for t in lfk]
         rrows = [int(t.numel()) for t in rpk]
         n = sum(lrows)
         out = [self.empty(n) for _ in range(3)]
-        torch.cuda.synchronize(self.device)
+        torch.cuda.current_stream(self.device).synchronize()  # inputs come from torch's stream; do not wait for RCCL's
         self.ctx.join_set_hash_skip_bits(skip_bits)
         try:
             got, stats = self.ctx.join_u32([t.data_ptr() for t in lfk], [t.data_ptr() for t in ly], lrows,
@@ -72,13 +97,27 @@ class GpuLocalOps:
         return out[0][:got], out[1][:got], out[2][:got], stats
 
 
-def _exchange(send: torch.Tensor, in_splits, out_splits, empty, group) -> torch.Tensor:
-    """Personalised all-to-all of a 1-D tensor.  RCCL/NCCL: all_to_all_single; backends
+class _Pending:
+    """An exchange in flight: .wait() returns the received tensor."""
+
+    def __init__(self, recv, work=None):
+        self.recv, self.work = recv, work
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+        return self.recv
+
+
+def _exchange(send: torch.Tensor, in_splits, out_splits, empty, group, async_op: bool = False):
+    """Personalised all-to-all of a 1-D tensor.  RCCL/NCCL: all_to_all_single (optionally
+    asynchronous, so it overlaps the partition kernels of the other table); backends
     without it (gloo on some builds): pairwise isend/irecv."""
     recv = empty(int(sum(out_splits)))
     try:
-        dist.all_to_all_single(recv, send, output_split_sizes=list(out_splits), input_split_sizes=list(in_splits), group=group)
-        return recv
+        work = dist.all_to_all_single(recv, send, output_split_sizes=list(out_splits), input_split_sizes=list(in_splits),
+                                      group=group, async_op=async_op)
+        return _Pending(recv, work) if async_op else recv
     except (RuntimeError, NotImplementedError):
         pass
     rank, world = dist.get_rank(group), dist.get_world_size(group)
@@ -100,7 +139,20 @@ def _exchange(send: torch.Tensor, in_splits, out_splits, empty, group) -> torch.
             reqs.append(dist.irecv(recv[ro[peer]:ro[peer + 1]], gp, group=group))
     for r in reqs:
         r.wait()
-    return recv
+    return _Pending(recv) if async_op else recv
+
+
+def _exchange_counts(cnt_in: torch.Tensor, world: int, group) -> torch.Tensor:
+    cnt_out = torch.empty_like(cnt_in)
+    try:
+        dist.all_to_all_single(cnt_out, cnt_in, group=group)
+        return cnt_out
+    except (RuntimeError, NotImplementedError):
+        per = cnt_in.numel() // world
+        gathered = [torch.empty_like(cnt_in) for _ in range(world)]
+        dist.all_gather(gathered, cnt_in, group=group)
+        rank = dist.get_rank(group)
+        return torch.stack([gt.view(world, per)[rank] for gt in gathered]).view(-1)
 
 
 def distributed_join(ops, left_batches: Sequence, right_batches: Sequence, group=None, timers: dict | None = None):
@@ -115,6 +167,25 @@ def distributed_join(ops, left_batches: Sequence, right_batches: Sequence, group
     if world & (world - 1):
         raise ValueError("the owner split uses the top log2(G) hash bits: world size must be a power of two")
     g = world.bit_length() - 1
+    rank = dist.get_rank(group)
+    if hasattr(ops, "partition_tuples"):
+        # zipped path: one int64 tensor per table; the left table's exchange overlaps the
+        # owner split of the right table (RCCL runs on its own stream)
+        lt, loff = ops.partition_tuples(lfk, ly, world)
+        l_in = [loff[p + 1] - loff[p] for p in range(world)]
+        dev = lt.device
+        l_out = [int(v) for v in _exchange_counts(torch.tensor(l_in, dtype=torch.int64, device=dev), world, group).cpu()]
+        pend_l = _exchange(lt, l_in, l_out, ops.empty_tuples, group, async_op=True)
+        rt, roff = ops.partition_tuples(rpk, rx, world)
+        r_in = [roff[p + 1] - roff[p] for p in range(world)]
+        r_out = [int(v) for v in _exchange_counts(torch.tensor(r_in, dtype=torch.int64, device=dev), world, group).cpu()]
+        RR = _exchange(rt, r_in, r_out, ops.empty_tuples, group)
+        RL = pend_l.wait()
+        if RL.is_cuda:
+            torch.cuda.current_stream(RL.device).synchronize()
+        fk, y, x, stats = ops.join_tuples(RL, RR, g)
+        sent = sum(l_in) + sum(r_in) - l_in[rank] - r_in[rank]
+        return fk, y, x, {"world": world, "stats": stats, "sent_rows": sent, "recv_left": sum(l_out), "recv_right": sum(r_out)}
     # (2) group by owner
     lk, lp, loff = ops.partition(lfk, ly, world)
     rk, rp, roff = ops.partition(rpk, rx, world)
@@ -140,6 +211,5 @@ def distributed_join(ops, left_batches: Sequence, right_batches: Sequence, group
     RRp = _exchange(_i32(rp), r_in, r_out, ops.empty, group)
     # (4) local join below the owner bits
     fk, y, x, stats = ops.join([RLk], [RLp], [RRk], [RRp], g)
-    rank = dist.get_rank(group)
     sent = sum(l_in) + sum(r_in) - l_in[rank] - r_in[rank]
     return fk, y, x, {"world": world, "stats": stats, "sent_rows": sent, "recv_left": sum(l_out), "recv_right": sum(r_out)}

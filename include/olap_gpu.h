@@ -153,6 +153,15 @@ int olap_partition_u32(olap_ctx* ctx, const uint32_t* const* key_ptrs,
                        uint32_t* out_payload, uint64_t out_capacity, int out_mem,
                        uint64_t* out_offsets);
 
+/* Same partitioning, but the (key, payload) tuples stay zipped: out_tuples[i] =
+ * key | (uint64_t)payload << 32 (device memory, 16-byte aligned, capacity in tuples).
+ * This is the send buffer of the multi-GPU owner split: partition p is the contiguous
+ * region [out_offsets[p], out_offsets[p+1]) for peer p. */
+int olap_partition_tuples_u32(olap_ctx* ctx, const uint32_t* const* key_ptrs,
+                              const uint32_t* const* payload_ptrs, const uint64_t* rows,
+                              uint64_t n_batches, int in_mem, uint32_t nr_partitions,
+                              uint64_t* out_tuples, uint64_t out_capacity, uint64_t* out_offsets);
+
 /* -------------------------------------------------------------------- join
  * Replaces JoinDpu::Run_internal (host/join/join_dpu.cc:168-400): radix
  * partition of both tables, then per partition kernel_hash_build
@@ -182,6 +191,14 @@ int olap_join_u32(olap_ctx* ctx, const uint32_t* const* left_fk_ptrs,
                   uint64_t n_right_batches, int in_mem, uint32_t* out_fk, uint32_t* out_y,
                   uint32_t* out_x, uint64_t out_capacity, int out_mem, uint64_t* out_rows,
                   olap_join_stats* stats /* may be NULL */);
+
+/* The same join on zipped tuples already resident in HBM (what a rank holds after the
+ * all-to-all): left_tuples[i] = fk | y << 32, right_tuples[i] = pk | x << 32, 16-byte
+ * aligned device arrays; outputs are device columns. */
+int olap_join_tuples_u32(olap_ctx* ctx, const uint64_t* left_tuples, uint64_t n_left,
+                         const uint64_t* right_tuples, uint64_t n_right, uint32_t* out_fk,
+                         uint32_t* out_y, uint32_t* out_x, uint64_t out_capacity, uint64_t* out_rows,
+                         olap_join_stats* stats /* may be NULL */);
 
 /* Tuning knobs (0 = default).  radix_bits_total < 0 keeps the automatic choice
  * ceil(log2(right_rows / 4096)). */

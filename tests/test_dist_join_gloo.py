@@ -40,13 +40,33 @@ class OracleLocalOps:
         return conv(fk), conv(y), conv(x), {"skip_bits": skip_bits}
 
 
+class OracleTupleOps(OracleLocalOps):
+    """Adds the zipped-tuple entry points, so distributed_join takes its tuple path (two
+    int64 exchanges, the left one asynchronous) like GpuLocalOps does."""
+
+    def empty_tuples(self, n):
+        return torch.empty(n, dtype=torch.int64)
+
+    def partition_tuples(self, keys, payload, nr_partitions):
+        ok, op, offs = self.partition(keys, payload, nr_partitions)
+        z = self._np(ok).astype(np.uint64) | (self._np(op).astype(np.uint64) << np.uint64(32))
+        return torch.from_numpy(z.view(np.int64).copy()), offs
+
+    def join_tuples(self, lt, rt, skip_bits=0):
+        unz = lambda t: (torch.from_numpy((t.numpy().view(np.uint64) & np.uint64(0xFFFFFFFF)).astype(np.uint32).view(np.int32)),
+                         torch.from_numpy((t.numpy().view(np.uint64) >> np.uint64(32)).astype(np.uint32).view(np.int32)))
+        lk, lp = unz(lt.contiguous())
+        rk, rp = unz(rt.contiguous())
+        return self.join([lk], [lp], [rk], [rp], skip_bits)
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, case, outdir):
+def _worker(rank, world, port, case, outdir, tuple_path):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -60,7 +80,7 @@ def _worker(rank, world, port, case, outdir):
         t = lambda a: torch.from_numpy(a.view(np.int32).copy())
         left = [(t(k), t(p)) for k, p in zip(cut(sl(fk)), cut(sl(y)))]
         right = [(t(k), t(p)) for k, p in zip(cut(sl(pk)), cut(sl(x)))]
-        ofk, oy, ox, info = distributed_join(OracleLocalOps(), left, right)
+        ofk, oy, ox, info = distributed_join(OracleTupleOps() if tuple_path else OracleLocalOps(), left, right)
         u = lambda tt: tt.contiguous().numpy().view(np.uint32)
         np.savez(os.path.join(outdir, f"rank{rank}.npz"), fk=u(ofk), y=u(oy), x=u(ox),
                  sent=np.array([info["sent_rows"]]), skip=np.array([info["stats"]["skip_bits"]]))
@@ -69,11 +89,11 @@ def _worker(rank, world, port, case, outdir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world,tuple_path", [(2, True), (2, False), (4, True)])
 @pytest.mark.parametrize("case", ["a", "b"])
-def test_distributed_join_gloo(tmp_path, world, case):
+def test_distributed_join_gloo(tmp_path, world, case, tuple_path):
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, case, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, case, str(tmp_path), tuple_path), nprocs=world, join=True)
     g = np.load(os.path.join(GOLDEN_DIR, "arrow_golden.npz"))
     shards = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
     bits = world.bit_length() - 1

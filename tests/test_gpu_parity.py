@@ -512,13 +512,29 @@ def test_multirank_join_loopback_on_one_gpu(dev, world):
     dev.gen_uniform_u32_at(exp.data_ptr(), fk.data_ptr(), n, dg.SEED, dg.STREAM_X)
     expect = dev.checksum_rows3_u32(fk.data_ptr(), y.data_ptr(), exp.data_ptr(), n)
     per = nb // world
+    # zipped path first: partition_tuples -> slices -> join_tuples
+    zs = []
+    for r in range(world):
+        sl = lambda t: [t[(r * per + b) * rows:(r * per + b + 1) * rows] for b in range(per)]
+        zs.append(ops.partition_tuples(sl(fk), sl(y), world) + ops.partition_tuples(sl(pk), sl(x), world))
+    bits = world.bit_length() - 1
+    zsum, zxor, zrows = 0, 0, 0
+    for r in range(world):
+        RL = torch.cat([z[0][z[1][r]:z[1][r + 1]] for z in zs])
+        RR = torch.cat([z[2][z[3][r]:z[3][r + 1]] for z in zs])
+        ofk, oy, ox, stats = ops.join_tuples(RL, RR, bits)
+        assert stats["missing_keys"] == 0
+        s, xo = dev.checksum_rows3_u32(ofk.data_ptr(), oy.data_ptr(), ox.data_ptr(), ofk.numel())
+        zsum = (zsum + s) & ((1 << 64) - 1)
+        zxor ^= xo
+        zrows += ofk.numel()
+    assert zrows == n and (zsum, zxor) == expect
     sends = []
     for r in range(world):          # every logical rank groups its batches by owner
         sl = lambda t: [t[(r * per + b) * rows:(r * per + b + 1) * rows] for b in range(per)]
         lk, lp, loff = ops.partition(sl(fk), sl(y), world)
         rk, rp, roff = ops.partition(sl(pk), sl(x), world)
         sends.append((lk, lp, loff, rk, rp, roff))
-    bits = world.bit_length() - 1
     tot_sum, tot_xor, tot_rows = 0, 0, 0
     for r in range(world):          # rank r receives region r of every sender
         cat = lambda i, o: torch.cat([s[i][s[o][r]:s[o][r + 1]] for s in sends])
