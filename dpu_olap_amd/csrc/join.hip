@@ -375,15 +375,23 @@ __global__ __launch_bounds__(kPBlock, 4) void k_part_scatter(PassSrc s, uint32_t
 // count << 56 | leading slots that belong to the previous workgroup << 60.
 constexpr int kWBlock = 1024;
 constexpr int kWTPT = kPTile / kWBlock;  // 8
-constexpr int kLine = 8;                 // tuples per 64-byte line
-constexpr int kRes = kLine - 1;
-constexpr uint32_t kWcLdsStage = 0;
-constexpr uint32_t kWcLdsRes = kWcLdsStage + kPTile * 8;
-constexpr uint32_t kWcLdsBm = kWcLdsRes + kRes * kMaxF * 8;
-constexpr uint32_t kWcLdsCl = kWcLdsBm + kMaxF * 16;
-constexpr uint32_t kWcLdsL2b = kWcLdsCl + (kMaxF + 4) * 4;
-constexpr uint32_t kWcLdsWtot = kWcLdsL2b + ((kPTile + kRes * kMaxF) / kLine) * 2;
-constexpr uint32_t kWcLds = kWcLdsWtot + (kWBlock / kWave) * 8 + 64;
+// LINE = tuples per emitted line: 8 (64 B) for up to 1024 buckets, 16 (128 B, a whole L2
+// line; scattered 128-B lines reach ~4.8 TB/s against ~3.6 TB/s for 64-B ones,
+// profiles/r1_ubench_rand_chunk_write.txt) for up to 512 buckets -- the LDS residue buffer
+// F * (LINE - 1) * 8 B is what bounds the fan-out.
+template <int LINE>
+struct WcLds {
+  static constexpr int kRes = LINE - 1;
+  static constexpr int kFmax = LINE == 8 ? 1024 : 512;
+  static constexpr uint32_t kStage = 0;
+  static constexpr uint32_t kResOff = kStage + kPTile * 8;
+  static constexpr uint32_t kBm = kResOff + kRes * kFmax * 8;
+  static constexpr uint32_t kCl = kBm + kFmax * 16;
+  static constexpr uint32_t kL2b = kCl + (kFmax + 4) * 4;
+  static constexpr uint32_t kWtot = kL2b + ((kPTile + kRes * kFmax) / LINE + 2) * 2;
+  static constexpr uint32_t kBytes = ((kWtot + 15) / 16) * 16 + (kWBlock / kWave) * 8 + 64;
+};
+constexpr int kLineAlign = 16;  // capacity regions are aligned for either line size
 
 // Capacity mode (CAPM, last pass only, one workgroup per input segment): no histogram
 // pre-pass.  Output bucket (seg, b) owns the fixed region [p * cap, (p + 1) * cap) with
@@ -392,24 +400,27 @@ constexpr uint32_t kWcLds = kWcLdsWtot + (kWBlock / kWave) * 8 + 64;
 // its region raises *overflow and drops the excess; the host then reruns the join with
 // exact (histogram) partitioning.
 struct CapOut {
-  uint32_t cap;       // tuples per region, multiple of kLine
+  uint32_t cap;       // tuples per region, multiple of kLineAlign
   uint32_t* cnt;      // [n_seg * F]
   uint64_t* dense;    // [n_seg * F]
   unsigned long long* overflow;
 };
 
-template <int SRC, bool CAPM>
+template <int SRC, bool CAPM, int LINE>
 __global__ __launch_bounds__(kWBlock) void k_part_scatter_wc(PassSrc s, uint32_t shift, uint32_t fbits,
                                                              const uint32_t* hist,
                                                              const uint64_t* seg_off_out, uint2* out,
                                                              CapOut co) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  uint2* stage = (uint2*)(smem + kWcLdsStage);
-  uint2* res = (uint2*)(smem + kWcLdsRes);          // [bucket * kRes + slot]
-  uint4* bm = (uint4*)(smem + kWcLdsBm);
-  uint32_t* cl = (uint32_t*)(smem + kWcLdsCl);
-  uint16_t* l2b = (uint16_t*)(smem + kWcLdsL2b);    // flush line -> bucket
-  uint64_t* wtot = (uint64_t*)(smem + kWcLdsWtot);  // per-wave (count | flush << 32)
+  using LDS = WcLds<LINE>;
+  constexpr int kLine = LINE, kRes = LINE - 1;
+  constexpr uint32_t kFld = 15u;  // residue / skip counts: 4-bit fields at bits 56 and 60
+  uint2* stage = (uint2*)(smem + LDS::kStage);
+  uint2* res = (uint2*)(smem + LDS::kResOff);        // [bucket * kRes + slot]
+  uint4* bm = (uint4*)(smem + LDS::kBm);
+  uint32_t* cl = (uint32_t*)(smem + LDS::kCl);
+  uint16_t* l2b = (uint16_t*)(smem + LDS::kL2b);     // flush line -> bucket
+  uint64_t* wtot = (uint64_t*)(smem + ((LDS::kWtot + 15) / 16) * 16);  // per-wave (count | flush << 32)
   const uint32_t F = 1u << fbits;
   const TileRange r = block_tiles<SRC>(s);
   const unsigned lane = lane_id();
@@ -454,7 +465,7 @@ __global__ __launch_bounds__(kWBlock) void k_part_scatter_wc(PassSrc s, uint32_t
       c = cl[b_own];
       const uint4 m = bm[b_own];
       w64 = ((uint64_t)m.w << 32) | m.z;
-      rr = (uint32_t)(w64 >> 56) & 7u;
+      rr = (uint32_t)(w64 >> 56) & kFld;
       c_app = c;
       if (CAPM && (w64 & 0x00FFFFFFFFFFFFFFull) - region + rr + c > co.cap) {
         c_app = 0;  // region full: drop this tile's tuples of the bucket, report
@@ -502,7 +513,7 @@ __global__ __launch_bounds__(kWBlock) void k_part_scatter_wc(PassSrc s, uint32_t
       const uint4 m = bm[b];
       const uint64_t w = ((uint64_t)m.w << 32) | m.z;
       const uint32_t j = v - m.x;  // even
-      const uint32_t r_old = (uint32_t)(w >> 56) & 7u, skip = (uint32_t)(w >> 60) & 7u;
+      const uint32_t r_old = (uint32_t)(w >> 56) & kFld, skip = (uint32_t)(w >> 60) & kFld;
       const uint2 t0 = j < r_old ? res[b * kRes + j] : stage[m.y + (j - r_old)];
       const uint2 t1 = j + 1 < r_old ? res[b * kRes + j + 1] : stage[m.y + (j + 1 - r_old)];
       uint2* dst = out + (w & 0x00FFFFFFFFFFFFFFull) + j;
@@ -516,7 +527,7 @@ __global__ __launch_bounds__(kWBlock) void k_part_scatter_wc(PassSrc s, uint32_t
     // (6) what is left of each bucket becomes its residue
     if (owner) {
       uint64_t g = w64 & 0x00FFFFFFFFFFFFFFull;
-      uint64_t skip = (w64 >> 60) & 7u;
+      uint64_t skip = (w64 >> 60) & kFld;
       uint32_t r_new;
       if (f) {
         const uint32_t nf = f - rr;  // new tuples that were flushed
@@ -546,7 +557,7 @@ __global__ __launch_bounds__(kWBlock) void k_part_scatter_wc(PassSrc s, uint32_t
   if (owner) {
     const uint4 m = bm[b_own];
     const uint64_t w = ((uint64_t)m.w << 32) | m.z;
-    const uint32_t r_old = (uint32_t)(w >> 56) & 7u, skip = (uint32_t)(w >> 60) & 7u;
+    const uint32_t r_old = (uint32_t)(w >> 56) & kFld, skip = (uint32_t)(w >> 60) & kFld;
     for (uint32_t j = skip; j < r_old; ++j) out[(w & 0x00FFFFFFFFFFFFFFull) + j] = res[b_own * kRes + j];
     count = (w & 0x00FFFFFFFFFFFFFFull) - region + r_old;
   }
@@ -806,7 +817,7 @@ struct SideOut {
 
 static uint32_t region_cap(uint64_t rows, uint64_t P) {
   const uint64_t avg = (rows + P - 1) / P;
-  return (uint32_t)align_up(avg + avg / 8 + 64, kLine);
+  return (uint32_t)align_up(avg + avg / 8 + 64, kLineAlign);
 }
 
 // The last pass may skip its histogram (capacity layout) when every workgroup owns whole
@@ -847,12 +858,16 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
                                     hipFuncAttributeMaxDynamicSharedMemorySize, kScatterLds));
   OLAP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_scatter<SRC_TUPLES>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, kScatterLds));
-  OLAP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_scatter_wc<SRC_COLS, false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, kWcLds));
-  OLAP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_scatter_wc<SRC_TUPLES, false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, kWcLds));
-  OLAP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_scatter_wc<SRC_TUPLES, true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, kWcLds));
+#define OLAP_WC_ATTR(SRCV, CAPV, LINEV)                                                                      \
+  OLAP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_scatter_wc<SRCV, CAPV, LINEV>),     \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, WcLds<LINEV>::kBytes))
+  OLAP_WC_ATTR(SRC_COLS, false, 8);
+  OLAP_WC_ATTR(SRC_COLS, false, 16);
+  OLAP_WC_ATTR(SRC_TUPLES, false, 8);
+  OLAP_WC_ATTR(SRC_TUPLES, false, 16);
+  OLAP_WC_ATTR(SRC_TUPLES, true, 8);
+  OLAP_WC_ATTR(SRC_TUPLES, true, 16);
+#undef OLAP_WC_ATTR
   const bool wc = ctx->scatter_variant == 0;  // write-combining scatter: 1 workgroup of 1024 per CU
   for (int i = 0; i < plan.passes; ++i) {
     const uint32_t fbits = plan.bits[i];
@@ -888,8 +903,14 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
       if (!so->cnt || !so->dense) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (capacity tables)");
       PhaseScope ps(ctx, PH_PART_SCATTER);
       CapOut co{so->cap, so->cnt, so->dense, d_overflow};
-      hipLaunchKernelGGL((k_part_scatter_wc<SRC_TUPLES, true>), dim3((unsigned)blocks), dim3(kWBlock), kWcLds, ctx->stream,
-                         src, shift, fbits, (const uint32_t*)nullptr, (const uint64_t*)nullptr, out, co);
+      if (fbits <= 9 && ctx->line16)
+        hipLaunchKernelGGL((k_part_scatter_wc<SRC_TUPLES, true, 16>), dim3((unsigned)blocks), dim3(kWBlock),
+                           WcLds<16>::kBytes, ctx->stream, src, shift, fbits, (const uint32_t*)nullptr,
+                           (const uint64_t*)nullptr, out, co);
+      else
+        hipLaunchKernelGGL((k_part_scatter_wc<SRC_TUPLES, true, 8>), dim3((unsigned)blocks), dim3(kWBlock),
+                           WcLds<8>::kBytes, ctx->stream, src, shift, fbits, (const uint32_t*)nullptr,
+                           (const uint64_t*)nullptr, out, co);
       OLAP_HIP(ctx, hipGetLastError());
       return OLAP_OK;
     }
@@ -912,12 +933,19 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
     }
     {
       PhaseScope ps(ctx, PH_PART_SCATTER);
-      if (wc && cols)
-        hipLaunchKernelGGL((k_part_scatter_wc<SRC_COLS, false>), dim3((unsigned)blocks), dim3(kWBlock), kWcLds, ctx->stream,
-                           src, shift, fbits, (const uint32_t*)hist, (const uint64_t*)seg_out, out, CapOut{});
+      const bool l16 = fbits <= 9 && ctx->line16;
+      if (wc && cols && l16)
+        hipLaunchKernelGGL((k_part_scatter_wc<SRC_COLS, false, 16>), dim3((unsigned)blocks), dim3(kWBlock), WcLds<16>::kBytes,
+                           ctx->stream, src, shift, fbits, (const uint32_t*)hist, (const uint64_t*)seg_out, out, CapOut{});
+      else if (wc && cols)
+        hipLaunchKernelGGL((k_part_scatter_wc<SRC_COLS, false, 8>), dim3((unsigned)blocks), dim3(kWBlock), WcLds<8>::kBytes,
+                           ctx->stream, src, shift, fbits, (const uint32_t*)hist, (const uint64_t*)seg_out, out, CapOut{});
+      else if (wc && l16)
+        hipLaunchKernelGGL((k_part_scatter_wc<SRC_TUPLES, false, 16>), dim3((unsigned)blocks), dim3(kWBlock), WcLds<16>::kBytes,
+                           ctx->stream, src, shift, fbits, (const uint32_t*)hist, (const uint64_t*)seg_out, out, CapOut{});
       else if (wc)
-        hipLaunchKernelGGL((k_part_scatter_wc<SRC_TUPLES, false>), dim3((unsigned)blocks), dim3(kWBlock), kWcLds, ctx->stream,
-                           src, shift, fbits, (const uint32_t*)hist, (const uint64_t*)seg_out, out, CapOut{});
+        hipLaunchKernelGGL((k_part_scatter_wc<SRC_TUPLES, false, 8>), dim3((unsigned)blocks), dim3(kWBlock), WcLds<8>::kBytes,
+                           ctx->stream, src, shift, fbits, (const uint32_t*)hist, (const uint64_t*)seg_out, out, CapOut{});
       else if (cols)
         hipLaunchKernelGGL((k_part_scatter<SRC_COLS>), dim3((unsigned)blocks), dim3(kPBlock), kScatterLds, ctx->stream,
                            src, shift, fbits, (const uint32_t*)hist, (const uint64_t*)seg_out, out);
@@ -1096,6 +1124,10 @@ int olap_set_tuning(olap_ctx* ctx, const char* key, int value) {
   if (!std::strcmp(key, "scatter_variant")) {
     if (value < 0 || value > 1) return ctx->fail(OLAP_ERR_INVALID, "scatter_variant must be 0 (write-combining) or 1 (tile-staged)");
     ctx->scatter_variant = value;
+    return OLAP_OK;
+  }
+  if (!std::strcmp(key, "line16")) {
+    ctx->line16 = value != 0;
     return OLAP_OK;
   }
   if (!std::strcmp(key, "capacity_mode")) {

@@ -259,12 +259,14 @@ def test_join_vs_arrow_golden(dev, golden, case, cfg, device):
         assert sum(stats["radix_bits"]) == cfg["bits"]
 
 
-@pytest.mark.parametrize("variant", [0, 1])
-@pytest.mark.parametrize("cfg", [dict(), dict(bits=12, max_bits=4), dict(bits=20)])
+@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("cfg", [dict(), dict(bits=12, max_bits=4), dict(bits=20), dict(bits=18)])
 def test_join_scatter_variants_agree(dev, golden, variant, cfg):
-    """Both scatter kernels (0 = write-combining, 1 = tile-staged) give the golden table, also
-    with the 10+10-bit plan of the SF=2048 benchmark (tiny partitions here)."""
-    dev.set_tuning("scatter_variant", variant)
+    """All scatter kernels (0 = write-combining 64-B lines, 1 = tile-staged, 2 = write-combining
+    with 128-B lines for passes of <= 512 buckets) give the golden table, also with the 10+10-bit
+    plan of the SF=2048 benchmark and a 9+9-bit plan (tiny partitions here)."""
+    dev.set_tuning("scatter_variant", 1 if variant == 1 else 0)
+    dev.set_tuning("line16", 1 if variant == 2 else 0)
     try:
         for case in ("a", "b"):
             lf = split_batches(golden[f"join_{case}_fk"], golden[f"join_{case}_left_rows"])
@@ -277,9 +279,10 @@ def test_join_scatter_variants_agree(dev, golden, variant, cfg):
             np.testing.assert_array_equal(x, golden[f"join_{case}_out_x"])
     finally:
         dev.set_tuning("scatter_variant", 0)
+        dev.set_tuning("line16", 0)
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_partition_variants_vs_oracle_multiset(dev, variant):
     o = _ops()
     rng = np.random.default_rng(11)
@@ -287,11 +290,19 @@ def test_partition_variants_vs_oracle_multiset(dev, variant):
     # heavy skew: one hot key and one hot bucket
     keys[0][:100000] = 12345
     pay = [np.arange(k.size, dtype=np.uint32) for k in keys]
-    dev.set_tuning("scatter_variant", variant)
+    dev.set_tuning("scatter_variant", 1 if variant == 1 else 0)
+    dev.set_tuning("line16", 1 if variant == 2 else 0)
     try:
-        parts = o.PartitionGpu(dev, list(zip(keys, pay)), 1024).Prepare().Run()
+        parts = o.PartitionGpu(dev, list(zip(keys, pay)), 1024 if variant != 2 else 512 * 512).Prepare().Run()
+        if variant == 2:  # 9+9-bit plan: fold the 2^18 partitions back to the top 10 bits
+            merged = []
+            for i in range(1024):
+                grp = parts[i * 256:(i + 1) * 256]
+                merged.append((np.concatenate([k for k, _ in grp]), np.concatenate([p for _, p in grp])))
+            parts = merged
     finally:
         dev.set_tuning("scatter_variant", 0)
+        dev.set_tuning("line16", 0)
     allk, allp = np.concatenate(keys), np.concatenate(pay)
     bucket = oracle.wang_hash_np(allk) >> np.uint32(22)
     gk = np.concatenate([k for k, _ in parts])
