@@ -75,6 +75,7 @@ struct olap_ctx {
   int max_bits_per_pass = 0;
   int scatter_variant = 0;  // 0 write-combining scatter, 1 tile-staged scatter (A/B)
   int probe_variant = 0;
+  int take_variant = 0;    // 0 auto, 1 never use the LDS-window kernel, 2 never use small tiles
   int line16 = 0;          // 1: 128-byte write-combining lines for passes of <= 512 buckets (measured: no gain yet, the kernel is not write-bound there)
   int capacity_mode = 1;   // last radix pass without histogram (fixed-capacity regions + exact fallback)
   int hash_skip_bits = 0;  // top hash bits already fixed by an upstream owner split

@@ -1134,6 +1134,10 @@ int olap_set_tuning(olap_ctx* ctx, const char* key, int value) {
     ctx->capacity_mode = value != 0;
     return OLAP_OK;
   }
+  if (!std::strcmp(key, "take_variant")) {
+    ctx->take_variant = value;
+    return OLAP_OK;
+  }
   if (!std::strcmp(key, "probe_variant")) {
     ctx->probe_variant = value;
     return OLAP_OK;

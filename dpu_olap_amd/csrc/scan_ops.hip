@@ -275,9 +275,10 @@ __global__ __launch_bounds__(kBlock) void k_filter_compact(ColView sv, const voi
 // Tiles over the index stream of each batch; indices loaded 16 B per lane,
 // values gathered (the batch's data buffer is L2 / Infinity-Cache resident while
 // its tiles are in flight), results stored 16 B per lane.
-template <typename T>
+template <typename T, int VPT>
 __global__ __launch_bounds__(kBlock) void k_take(ColView iv, const void* const* data_ptrs,
                                                  const void* const* idx_ptrs, void* const* out_ptrs) {
+  constexpr int kVecPerThread = VPT;
   constexpr uint32_t TILE = kBlock * kVecPerThread * 4;  // indices per tile
   for (uint64_t tile = blockIdx.x; tile < iv.total_units; tile += gridDim.x) {
     Loc l = locate(iv, tile);
@@ -311,6 +312,61 @@ __global__ __launch_bounds__(kBlock) void k_take(ColView iv, const void* const* 
       }
     } else {
       for (uint32_t i = threadIdx.x; i < n; i += kBlock) out[i] = data[idx[i]];
+    }
+  }
+}
+
+// Small batches (the reference's 64 Ki-row shape): the random 4-byte gathers would pull a
+// whole 64-byte line each from HBM.  Instead one workgroup owns a batch, streams its data
+// through LDS window by window (coalesced 16 B/lane loads) and serves the gathers from LDS;
+// indices and results of the workgroup stay in registers, so indices are read once and the
+// output is written once, coalesced.  Two workgroups of 512 per CU (64 KiB window each).
+constexpr int kTBlock = 512;
+constexpr int kTWindowBytes = 64 << 10;
+constexpr int kTIdxPerThread = 16;  // up to 8192 indices per batch are held in registers
+
+template <typename T>
+__global__ __launch_bounds__(kTBlock, 4) void k_take_lds(ColView dv, ColView iv, uint32_t nb,
+                                                         const void* const* data_ptrs,
+                                                         const void* const* idx_ptrs, void* const* out_ptrs) {
+  __shared__ __attribute__((aligned(16))) unsigned char s_win[kTWindowBytes];
+  constexpr uint32_t W = kTWindowBytes / sizeof(T);  // elements per window
+  T* win = reinterpret_cast<T*>(s_win);
+  for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
+    const uint32_t rows = (uint32_t)batch_rows(dv, b), m = (uint32_t)batch_rows(iv, b);
+    const T* data = (const T*)data_ptrs[b];
+    const uint32_t* idx = (const uint32_t*)idx_ptrs[b];
+    T* out = (T*)out_ptrs[b];
+    uint32_t ix[kTIdxPerThread];
+    T val[kTIdxPerThread];
+#pragma unroll
+    for (int k = 0; k < kTIdxPerThread; ++k) {
+      const uint32_t i = k * kTBlock + threadIdx.x;
+      ix[k] = i < m ? idx[i] : 0xFFFFFFFFu;
+      val[k] = 0;
+    }
+    const bool vec_ok = (((uintptr_t)data) & 15) == 0;
+    for (uint32_t w0 = 0; w0 < rows; w0 += W) {
+      const uint32_t wn = min(W, rows - w0);
+      __syncthreads();  // previous window fully consumed
+      if (vec_ok && wn == W) {
+        const uint4* src = (const uint4*)(data + w0);
+#pragma unroll
+        for (int j = 0; j < kTWindowBytes / 16 / kTBlock; ++j) ((uint4*)s_win)[j * kTBlock + threadIdx.x] = src[j * kTBlock + threadIdx.x];
+      } else {
+        for (uint32_t i = threadIdx.x; i < wn; i += kTBlock) win[i] = data[w0 + i];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < kTIdxPerThread; ++k) {
+        const uint32_t rel = ix[k] - w0;  // unsigned: out-of-window (and the 0xFFFFFFFF filler) fail the test
+        if (rel < wn) val[k] = win[rel];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kTIdxPerThread; ++k) {
+      const uint32_t i = k * kTBlock + threadIdx.x;
+      if (i < m) out[i] = val[k];
     }
   }
 }
@@ -498,9 +554,22 @@ static int run_take(olap_ctx* ctx, const void* const* data_ptrs, const uint64_t*
       for (uint64_t b = b0; b < b1; ++b) need += align_up(idx_rows[b] * eb, 256);
     OLAP_TRY(pinned_begin(ctx, (cnt + 1) * 8 * 8 + 4096));
     OLAP_TRY(ws_begin(ctx, need));
+    // choose the kernel by batch shape
+    uint64_t max_data = 0, max_idx = 0;
+    for (uint64_t b = b0; b < b1; ++b) {
+      if (data_rows[b] > max_data) max_data = data_rows[b];
+      if (idx_rows[b] > max_idx) max_idx = idx_rows[b];
+    }
+    const bool lds_path = ctx->take_variant != 1 && max_idx <= (uint64_t)kTBlock * kTIdxPerThread &&
+                          max_data * eb <= 8ull * kTWindowBytes && cnt >= (uint64_t)ctx->compute_units;
+    // large batches, experiment knob (take_variant = 3): small tiles keep fewer batches in
+    // flight; measured no gain at SF=2048 -- the 64-B random gathers already move a whole
+    // 128-B L2 line each (2^30 gathers in 21.9 ms = 6.3 TB/s of lines), so this stays off.
+    const bool small_tiles = !lds_path && max_data * eb > (1ull << 20) && ctx->take_variant == 3;
+    const uint32_t tile_sel = small_tiles ? kBlock * 4 : TILE;
     ColumnSet ds, is;
-    OLAP_TRY(build_column_set(ctx, dcols, 1, &eb, data_rows + b0, cnt, in_mem, TILE, &ds));
-    OLAP_TRY(build_column_set(ctx, icols, 1, &ib, idx_rows + b0, cnt, in_mem, TILE, &is));
+    OLAP_TRY(build_column_set(ctx, dcols, 1, &eb, data_rows + b0, cnt, in_mem, tile_sel, &ds));
+    OLAP_TRY(build_column_set(ctx, icols, 1, &ib, idx_rows + b0, cnt, in_mem, tile_sel, &is));
     void** h_out = (void**)pinned_alloc(ctx, (cnt ? cnt : 1) * 8);
     void** d_out_tbl = (void**)ws_alloc(ctx, (cnt ? cnt : 1) * 8);
     if (!h_out || !d_out_tbl) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted");
@@ -517,8 +586,16 @@ static int run_take(olap_ctx* ctx, const void* const* data_ptrs, const uint64_t*
     OLAP_HIP(ctx, hipMemcpyAsync(d_out_tbl, h_out, (cnt ? cnt : 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     if (is.view.total_units) {
       PhaseScope ps(ctx, PH_TAKE);
-      hipLaunchKernelGGL((k_take<T>), dim3(grid_for(ctx, is.view.total_units, 8)), dim3(kBlock), 0, ctx->stream,
-                         is.view, ds.dev_ptr_tables[0], is.dev_ptr_tables[0], (void* const*)d_out_tbl);
+      if (lds_path) {
+        hipLaunchKernelGGL((k_take_lds<T>), dim3(grid_for(ctx, cnt, 2)), dim3(kTBlock), 0, ctx->stream, ds.view, is.view,
+                           (uint32_t)cnt, ds.dev_ptr_tables[0], is.dev_ptr_tables[0], (void* const*)d_out_tbl);
+      } else if (small_tiles) {
+        hipLaunchKernelGGL((k_take<T, 1>), dim3(grid_for(ctx, is.view.total_units, 8)), dim3(kBlock), 0, ctx->stream,
+                           is.view, ds.dev_ptr_tables[0], is.dev_ptr_tables[0], (void* const*)d_out_tbl);
+      } else {
+        hipLaunchKernelGGL((k_take<T, 4>), dim3(grid_for(ctx, is.view.total_units, 8)), dim3(kBlock), 0, ctx->stream,
+                           is.view, ds.dev_ptr_tables[0], is.dev_ptr_tables[0], (void* const*)d_out_tbl);
+      }
       OLAP_HIP(ctx, hipGetLastError());
     }
     if (out_mem == OLAP_MEM_HOST) {

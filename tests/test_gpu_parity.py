@@ -559,3 +559,45 @@ def test_multirank_join_loopback_on_one_gpu(dev, world):
         tot_xor ^= xo
         tot_rows += ofk.numel()
     assert tot_rows == n and (tot_sum, tot_xor) == expect
+
+
+@pytest.mark.parametrize("t", ["u32", "i64"])
+def test_take_lds_window_kernel_many_small_batches(dev, t):
+    """>= #CU batches of <= 512 KiB with <= 8192 indices each take the LDS-window kernel
+    (data streamed through LDS, indices / results in registers); ragged sizes, partial windows."""
+    o = _ops()
+    rng = np.random.default_rng(99)
+    dt = TYPES[t]
+    nb = 300
+    rows = [65536] * nb
+    rows[3], rows[7], rows[11] = 1, 40000, 65537 if t == "u32" else 16385
+    data = [rng.integers(0, 1 << 31, size=r, dtype=np.int64).astype(dt) for r in rows]
+    idx = [rng.integers(0, r, size=8192, dtype=np.uint32) for r in rows]
+    idx[5] = idx[5][:17]
+    idx[6] = idx[6][:0]
+    res = o.TakeGpu(dev, [dev.to_device(d) for d in data], [dev.to_device(i) for i in idx]).Prepare().Run()
+    for b in list(range(0, 16)) + [nb - 1]:
+        np.testing.assert_array_equal(dev.to_host(res[b]), oracle.take(data[b], idx[b]))
+    dev.set_tuning("take_variant", 1)  # same through the direct-gather kernel
+    try:
+        res2 = o.TakeGpu(dev, [dev.to_device(d) for d in data[:16]] + [dev.to_device(d) for d in data[16:]],
+                         [dev.to_device(i) for i in idx]).Prepare().Run()
+    finally:
+        dev.set_tuning("take_variant", 0)
+    for b in (0, 3, 5, 7, 11, nb - 1):
+        np.testing.assert_array_equal(dev.to_host(res2[b]), oracle.take(data[b], idx[b]))
+
+
+def test_take_large_batches_small_tile_kernel(dev):
+    o = _ops()
+    rng = np.random.default_rng(5)
+    data = [rng.integers(0, 1 << 32, size=(1 << 20) + 3, dtype=np.uint32) for _ in range(3)]
+    idx = [rng.integers(0, d.size, size=100003, dtype=np.uint32) for d in data]
+    for variant in (0, 3):
+        dev.set_tuning("take_variant", variant)
+        try:
+            res = o.TakeGpu(dev, [dev.to_device(d) for d in data], [dev.to_device(i) for i in idx]).Prepare().Run()
+        finally:
+            dev.set_tuning("take_variant", 0)
+        for b in range(3):
+            np.testing.assert_array_equal(dev.to_host(res[b]), oracle.take(data[b], idx[b]))
