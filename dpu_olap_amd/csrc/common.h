@@ -77,6 +77,8 @@ struct olap_ctx {
   int probe_variant = 0;
   int take_variant = 0;    // 0 auto, 1 never use the LDS-window kernel, 2 never use small tiles
   int line16 = 0;          // 1: 128-byte write-combining lines for passes of <= 512 buckets (measured: no gain yet, the kernel is not write-bound there)
+  int direct_table = 1;    // collision-free direct-address LDS table when <= 14 hash bits remain (0: always probe)
+  int wc_geometry = 2;     // 2: passes of <= 512 buckets use 512-thread workgroups on 4096-tuple tiles, two per CU
   int capacity_mode = 1;   // last radix pass without histogram (fixed-capacity regions + exact fallback)
   int hash_skip_bits = 0;  // top hash bits already fixed by an upstream owner split
 

@@ -64,7 +64,7 @@ struct TileRange {
   uint32_t seg;
 };
 
-template <int SRC>
+template <int SRC, int TILE = kPTile>
 __device__ __forceinline__ TileRange block_tiles(const PassSrc& s) {
   TileRange r;
   if (SRC == SRC_COLS) {
@@ -79,7 +79,7 @@ __device__ __forceinline__ TileRange block_tiles(const PassSrc& s) {
     r.lo = s.seg_off[r.seg];
     r.hi = s.seg_off[r.seg + 1];
     r.a = r.lo & ~1ull;
-    const uint64_t tiles = (r.hi - r.a + kPTile - 1) / kPTile;
+    const uint64_t tiles = (r.hi - r.a + TILE - 1) / TILE;
     const uint64_t q = (tiles + s.blocks_per_seg - 1) / s.blocks_per_seg;
     r.t0 = min((uint64_t)j * q, tiles);
     r.t1 = min(r.t0 + q, tiles);
@@ -98,10 +98,10 @@ struct ColsCursor {
 };
 
 // Loads one tile: kPTile / BLOCK tuples per thread, valid bits in the returned mask.
-template <int SRC, int BLOCK, bool WANT_PAYLOAD>
+template <int SRC, int BLOCK, bool WANT_PAYLOAD, int TILE = kPTile>
 __device__ __forceinline__ uint32_t load_tile(const PassSrc& s, const TileRange& r, uint64_t tile, ColsCursor& cur,
-                                              uint32_t (&key)[kPTile / BLOCK], uint32_t (&pay)[kPTile / BLOCK]) {
-  constexpr int TPT = kPTile / BLOCK;
+                                              uint32_t (&key)[TILE / BLOCK], uint32_t (&pay)[TILE / BLOCK]) {
+  constexpr int TPT = TILE / BLOCK;
   uint32_t mask = 0;
   if (SRC == SRC_COLS) {
     const Loc l = locate(s.v, tile);
@@ -113,12 +113,12 @@ __device__ __forceinline__ uint32_t load_tile(const PassSrc& s, const TileRange&
       cur.row0 = batch_row0(s.v, l.batch);
     }
     const uint64_t rows = cur.rows;
-    const uint64_t r0 = l.local_unit * kPTile;
-    const uint32_t n = (uint32_t)min((uint64_t)kPTile, rows - r0);
+    const uint64_t r0 = l.local_unit * TILE;
+    const uint32_t n = (uint32_t)min((uint64_t)TILE, rows - r0);
     const uint32_t* kp = cur.kp + r0;
     const uint32_t* pp = cur.pp ? cur.pp + r0 : nullptr;
     const uint32_t rowid0 = (uint32_t)(cur.row0 + r0);
-    const bool fast = n == kPTile && ((((uintptr_t)kp) | ((uintptr_t)pp)) & 15) == 0;
+    const bool fast = n == TILE && ((((uintptr_t)kp) | ((uintptr_t)pp)) & 15) == 0;
     if (fast) {
       uint4 kv[TPT / 4], pv[TPT / 4];
 #pragma unroll
@@ -163,8 +163,8 @@ __device__ __forceinline__ uint32_t load_tile(const PassSrc& s, const TileRange&
       }
     }
   } else {
-    const uint64_t base = r.a + tile * (uint64_t)kPTile;
-    if (base >= r.lo && base + kPTile <= r.hi) {  // whole tile inside the segment (uniform)
+    const uint64_t base = r.a + tile * (uint64_t)TILE;
+    if (base >= r.lo && base + TILE <= r.hi) {  // whole tile inside the segment (uniform)
       const uint4* tv = (const uint4*)(s.tuples + base);
 #pragma unroll
       for (int j = 0; j < TPT / 2; ++j) {
@@ -199,19 +199,19 @@ __device__ __forceinline__ uint32_t load_tile(const PassSrc& s, const TileRange&
 }
 
 // ------------------------------------------------------------------ hist
-template <int SRC, int BLOCK>
+template <int SRC, int BLOCK, int TILE = kPTile>
 __global__ __launch_bounds__(BLOCK) void k_part_hist(PassSrc s, uint32_t shift, uint32_t fbits,
                                                      uint32_t* hist) {
-  constexpr int TPT = kPTile / BLOCK;
+  constexpr int TPT = TILE / BLOCK;
   __shared__ uint32_t cl[kMaxF];
   const uint32_t F = 1u << fbits;
   for (uint32_t b = threadIdx.x; b < F; b += BLOCK) cl[b] = 0;
   __syncthreads();
-  const TileRange r = block_tiles<SRC>(s);
+  const TileRange r = block_tiles<SRC, TILE>(s);
   ColsCursor cur;
   for (uint64_t tile = r.t0; tile < r.t1; ++tile) {
     uint32_t key[TPT], pay[TPT];
-    const uint32_t mask = load_tile<SRC, BLOCK, false>(s, r, tile, cur, key, pay);
+    const uint32_t mask = load_tile<SRC, BLOCK, false, TILE>(s, r, tile, cur, key, pay);
 #pragma unroll
     for (int i = 0; i < TPT; ++i) {
       if (mask & (1u << i)) atomicAdd(&cl[(wang_hash(key[i]) >> shift) & (F - 1)], 1u);
@@ -379,17 +379,20 @@ constexpr int kWTPT = kPTile / kWBlock;  // 8
 // line; scattered 128-B lines reach ~4.8 TB/s against ~3.6 TB/s for 64-B ones,
 // profiles/r1_ubench_rand_chunk_write.txt) for up to 512 buckets -- the LDS residue buffer
 // F * (LINE - 1) * 8 B is what bounds the fan-out.
-template <int LINE>
+// Geometry: BLOCK threads work on tiles of TILE tuples; BLOCK >= max buckets (one bucket per
+// owner thread).  {1024, 8192}: one workgroup per CU, up to 1024 buckets.  {512, 4096}: two
+// workgroups per CU (their phases overlap), up to 512 buckets.
+template <int LINE, int BLOCK = kWBlock, int TILE = kPTile>
 struct WcLds {
   static constexpr int kRes = LINE - 1;
-  static constexpr int kFmax = LINE == 8 ? 1024 : 512;
+  static constexpr int kFmax = (LINE == 8 ? 1024 : 512) < BLOCK ? (LINE == 8 ? 1024 : 512) : BLOCK;
   static constexpr uint32_t kStage = 0;
-  static constexpr uint32_t kResOff = kStage + kPTile * 8;
+  static constexpr uint32_t kResOff = kStage + TILE * 8;
   static constexpr uint32_t kBm = kResOff + kRes * kFmax * 8;
   static constexpr uint32_t kCl = kBm + kFmax * 16;
   static constexpr uint32_t kL2b = kCl + (kFmax + 4) * 4;
-  static constexpr uint32_t kWtot = kL2b + ((kPTile + kRes * kFmax) / LINE + 2) * 2;
-  static constexpr uint32_t kBytes = ((kWtot + 15) / 16) * 16 + (kWBlock / kWave) * 8 + 64;
+  static constexpr uint32_t kWtot = kL2b + ((TILE + kRes * kFmax) / LINE + 2) * 2;
+  static constexpr uint32_t kBytes = ((kWtot + 15) / 16) * 16 + (BLOCK / kWave) * 8 + 64;
 };
 constexpr int kLineAlign = 16;  // capacity regions are aligned for either line size
 
@@ -406,13 +409,14 @@ struct CapOut {
   unsigned long long* overflow;
 };
 
-template <int SRC, bool CAPM, int LINE>
-__global__ __launch_bounds__(kWBlock) void k_part_scatter_wc(PassSrc s, uint32_t shift, uint32_t fbits,
+template <int SRC, bool CAPM, int LINE, int BLOCK = kWBlock, int TILE = kPTile>
+__global__ __launch_bounds__(BLOCK) void k_part_scatter_wc(PassSrc s, uint32_t shift, uint32_t fbits,
                                                              const uint32_t* hist,
                                                              const uint64_t* seg_off_out, uint2* out,
                                                              CapOut co) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  using LDS = WcLds<LINE>;
+  using LDS = WcLds<LINE, BLOCK, TILE>;
+  constexpr int kWTPT = TILE / BLOCK;
   constexpr int kLine = LINE, kRes = LINE - 1;
   constexpr uint32_t kFld = 15u;  // residue / skip counts: 4-bit fields at bits 56 and 60
   uint2* stage = (uint2*)(smem + LDS::kStage);
@@ -422,10 +426,10 @@ __global__ __launch_bounds__(kWBlock) void k_part_scatter_wc(PassSrc s, uint32_t
   uint16_t* l2b = (uint16_t*)(smem + LDS::kL2b);     // flush line -> bucket
   uint64_t* wtot = (uint64_t*)(smem + ((LDS::kWtot + 15) / 16) * 16);  // per-wave (count | flush << 32)
   const uint32_t F = 1u << fbits;
-  const TileRange r = block_tiles<SRC>(s);
+  const TileRange r = block_tiles<SRC, TILE>(s);
   const unsigned lane = lane_id();
   const unsigned wave = threadIdx.x / kWave;
-  const uint32_t b_own = threadIdx.x;  // kWBlock >= kMaxF: one bucket per thread
+  const uint32_t b_own = threadIdx.x;  // BLOCK >= kMaxF: one bucket per thread
   const bool owner = b_own < F;
   uint64_t region = 0;  // CAPM: first tuple index of this thread's bucket region
   if (owner) {
@@ -445,7 +449,7 @@ __global__ __launch_bounds__(kWBlock) void k_part_scatter_wc(PassSrc s, uint32_t
   uint32_t key[kWTPT], pay[kWTPT], nkey[kWTPT], npay[kWTPT];
   uint32_t mask = 0, nmask = 0;
   ColsCursor cur;
-  if (r.t0 < r.t1) mask = load_tile<SRC, kWBlock, true>(s, r, r.t0, cur, key, pay);
+  if (r.t0 < r.t1) mask = load_tile<SRC, BLOCK, true, TILE>(s, r, r.t0, cur, key, pay);
   for (uint64_t tile = r.t0; tile < r.t1; ++tile) {
     // (2) bucket + rank of every tuple
     uint32_t br[kWTPT];
@@ -484,7 +488,7 @@ __global__ __launch_bounds__(kWBlock) void k_part_scatter_wc(PassSrc s, uint32_t
     __syncthreads();
     uint64_t pre = incl - pair, tot = 0;
 #pragma unroll 1
-    for (int w = 0; w < kWBlock / kWave; ++w) {
+    for (int w = 0; w < BLOCK / kWave; ++w) {
       const uint64_t t = wtot[w];
       if ((unsigned)w < wave) pre += t;
       tot += t;
@@ -504,11 +508,11 @@ __global__ __launch_bounds__(kWBlock) void k_part_scatter_wc(PassSrc s, uint32_t
     }
     // next tile's loads fly during the copy-out
     nmask = 0;
-    if (tile + 1 < r.t1) nmask = load_tile<SRC, kWBlock, true>(s, r, tile + 1, cur, nkey, npay);
+    if (tile + 1 < r.t1) nmask = load_tile<SRC, BLOCK, true, TILE>(s, r, tile + 1, cur, nkey, npay);
     __syncthreads();
     // (5) copy-out: 4 consecutive lanes write one aligned 64-byte line, 16 B (2 tuples) each
 #pragma unroll 1
-    for (uint32_t v = threadIdx.x * 2; v < V; v += kWBlock * 2) {
+    for (uint32_t v = threadIdx.x * 2; v < V; v += BLOCK * 2) {
       const uint32_t b = l2b[v / kLine];
       const uint4 m = bm[b];
       const uint64_t w = ((uint64_t)m.w << 32) | m.z;
@@ -737,6 +741,154 @@ __global__ __launch_bounds__(kJBlock, 4) void k_join_probe(PartView RV, PartView
   if (threadIdx.x == 0) atomicMax(&counters[3], (unsigned long long)my_max);
 }
 
+// ------------------------------------------- build + probe, direct-address table
+// Every step of the Wang hash (partition.c:20-28) is invertible modulo 2^32, so DISTINCT
+// keys have DISTINCT hashes.  All keys of one final partition share the top
+// (skip + radix) hash bits; when at most kDirectBits bits remain below them, the remaining
+// bits index an LDS table without any collision -- for ANY key set, not only dense ones:
+// no probing, no compare-and-swap; an equal key simply lands on its own slot again (the
+// reference's overwrite, hashtable.c:133).  16384 slots x (key, value) = 128 KiB, one
+// workgroup of 1024 per CU; partitions hold up to 16 Ki build rows, which lets the radix
+// passes stop at 512 buckets each (two scatter workgroups per CU).
+constexpr int kDirectBits = 14;
+constexpr int kDSlots = 1 << kDirectBits;
+constexpr int kDBlock = 1024;
+
+__global__ __launch_bounds__(kDBlock) void k_join_probe_direct(PartView RV, PartView LV, uint32_t nparts,
+                                                               uint32_t table_bits, uint32_t* out_fk,
+                                                               uint32_t* out_y, uint32_t* out_x,
+                                                               uint32_t pair_store_ok, unsigned long long* counters) {
+  __shared__ uint32_t s_keys[kDSlots];
+  __shared__ uint32_t s_vals[kDSlots];
+  __shared__ uint32_t s_sp[2];  // the one key equal to the empty marker: {present, value}
+  const uint2* R = RV.t;
+  const uint2* L = LV.t;
+  const uint32_t slots = 1u << table_bits, smask = slots - 1;
+  uint32_t my_miss = 0, my_dup = 0, my_clash = 0;
+  uint64_t my_max = 0;
+  for (uint32_t p = blockIdx.x; p < nparts; p += gridDim.x) {
+    const uint64_t rlo = RV.cap ? (uint64_t)p * RV.cap : RV.off[p];
+    const uint64_t rhi = RV.cap ? rlo + RV.cnt[p] : RV.off[p + 1];
+    const uint64_t llo = LV.cap ? (uint64_t)p * LV.cap : LV.off[p];
+    const uint64_t lhi = LV.cap ? llo + LV.cnt[p] : LV.off[p + 1];
+    const uint64_t n_r = rhi - rlo, n_l = lhi - llo;
+    const uint64_t delta = (LV.cap ? LV.dense[p] : llo) - llo;
+    const uint32_t pair_store = pair_store_ok && (delta & 1) == 0;
+    if (n_r > my_max) my_max = n_r;
+    if (n_l == 0) continue;
+    for (uint32_t i = threadIdx.x; i < slots; i += kDBlock) s_keys[i] = kEmpty;
+    if (threadIdx.x == 0) s_sp[0] = 0;
+    __syncthreads();
+    {  // build
+      const uint64_t a = rlo & ~1ull;
+      const uint64_t span = rhi - a;
+      for (uint64_t base = 0; base < span; base += kDBlock * 2 * kJU) {
+        uint4 v[kJU];
+#pragma unroll
+        for (int u = 0; u < kJU; ++u) {
+          const uint64_t i0 = base + (uint64_t)(u * kDBlock + threadIdx.x) * 2;
+          v[u] = make_uint4(0, 0, 0, 0);
+          if (i0 + 1 < span) {
+            v[u] = *(const uint4*)(R + a + i0);
+          } else if (i0 < span) {
+            const uint2 t1 = R[a + i0];
+            v[u].x = t1.x;
+            v[u].y = t1.y;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kJU; ++u) {
+          const uint64_t i0 = a + base + (uint64_t)(u * kDBlock + threadIdx.x) * 2;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const uint32_t k = h ? v[u].z : v[u].x, val = h ? v[u].w : v[u].y;
+            if (i0 + h < rlo || i0 + h >= rhi) continue;
+            if (k == kEmpty) {
+              s_sp[1] = val;
+              if (atomicExch(&s_sp[0], 1u)) ++my_dup;
+            } else {
+              const uint32_t slot = wang_hash(k) & smask;
+              const uint32_t old = atomicExch(&s_keys[slot], k);
+              s_vals[slot] = val;
+              if (old == k) ++my_dup;                 // equal key overwrites (hashtable.c:133)
+              else if (old != kEmpty) ++my_clash;     // impossible for keys of one partition
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    {  // probe + take of the right payload
+      const uint64_t a = llo & ~1ull;
+      const uint64_t span = lhi - a;
+      for (uint64_t base = 0; base < span; base += kDBlock * 2 * kJU) {
+        uint4 v[kJU];
+#pragma unroll
+        for (int u = 0; u < kJU; ++u) {
+          const uint64_t i0 = base + (uint64_t)(u * kDBlock + threadIdx.x) * 2;
+          v[u] = make_uint4(0, 0, 0, 0);
+          if (i0 + 1 < span) {
+            v[u] = *(const uint4*)(L + a + i0);
+          } else if (i0 < span) {
+            const uint2 t1 = L[a + i0];
+            v[u].x = t1.x;
+            v[u].y = t1.y;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kJU; ++u) {
+          const uint64_t i0 = a + base + (uint64_t)(u * kDBlock + threadIdx.x) * 2;
+          uint32_t xs[2] = {0, 0};
+          bool ok[2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const uint32_t k = h ? v[u].z : v[u].x;
+            ok[h] = i0 + h >= llo && i0 + h < lhi;
+            if (!ok[h]) continue;
+            bool hit;
+            if (k == kEmpty) {
+              hit = s_sp[0] != 0;
+              xs[h] = s_sp[1];
+            } else {
+              const uint32_t slot = wang_hash(k) & smask;
+              hit = s_keys[slot] == k;
+              xs[h] = s_vals[slot];
+            }
+            if (!hit) ++my_miss;
+          }
+          const uint64_t o = i0 + delta;
+          if (ok[0] && ok[1] && pair_store) {
+            *(uint2*)(out_fk + o) = make_uint2(v[u].x, v[u].z);
+            *(uint2*)(out_y + o) = make_uint2(v[u].y, v[u].w);
+            *(uint2*)(out_x + o) = make_uint2(xs[0], xs[1]);
+          } else {
+            if (ok[0]) {
+              out_fk[o] = v[u].x;
+              out_y[o] = v[u].y;
+              out_x[o] = xs[0];
+            }
+            if (ok[1]) {
+              out_fk[o + 1] = v[u].z;
+              out_y[o + 1] = v[u].w;
+              out_x[o + 1] = xs[1];
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  const uint64_t wm = wave_reduce_add((uint64_t)my_miss);
+  const uint64_t wd = wave_reduce_add((uint64_t)my_dup);
+  const uint64_t wc = wave_reduce_add((uint64_t)my_clash);
+  if (lane_id() == 0) {
+    if (wm) atomicAdd(&counters[0], (unsigned long long)wm);
+    if (wd) atomicAdd(&counters[1], (unsigned long long)wd);
+    if (wc) atomicAdd(&counters[2], (unsigned long long)wc);  // reported like a table overflow
+  }
+  if (threadIdx.x == 0) atomicMax(&counters[3], (unsigned long long)my_max);
+}
+
 __global__ __launch_bounds__(256) void k_unzip(const uint2* t, uint64_t n, uint32_t* keys, uint32_t* pay) {
   for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
     const uint2 v = t[i];
@@ -829,6 +981,19 @@ static bool capacity_eligible(const olap_ctx* ctx, uint64_t rows, const PassPlan
   return n_seg_last >= (uint64_t)ctx->compute_units && rows / P >= 512;
 }
 
+constexpr int kW2Block = 512;   // geometry 2 of the write-combining scatter: two workgroups per CU
+constexpr int kW2Tile = 4096;
+constexpr uint32_t kWc2Lds = WcLds<8, kW2Block, kW2Tile>::kBytes;
+
+static bool pass_uses_geometry2(const olap_ctx* ctx, uint32_t fbits) {
+  return ctx->scatter_variant == 0 && ctx->wc_geometry == 2 && !ctx->line16 && fbits <= 9;
+}
+
+// Tile size (rows per unit of the column view) pass 0 will use for `plan`.
+static uint32_t pass0_tile(const olap_ctx* ctx, const PassPlan& plan) {
+  return pass_uses_geometry2(ctx, plan.bits[0]) ? kW2Tile : kPTile;
+}
+
 // Input of pass 0: the batched columns `cs`, or (tuple_in != nullptr) an array of tuple_n
 // (key, payload) tuples already in HBM -- what a rank receives from the all-to-all.
 static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, const uint2* tuple_in,
@@ -868,7 +1033,14 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
   OLAP_WC_ATTR(SRC_TUPLES, true, 8);
   OLAP_WC_ATTR(SRC_TUPLES, true, 16);
 #undef OLAP_WC_ATTR
-  const bool wc = ctx->scatter_variant == 0;  // write-combining scatter: 1 workgroup of 1024 per CU
+#define OLAP_WC2_ATTR(SRCV, CAPV)                                                                                      \
+  OLAP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_scatter_wc<SRCV, CAPV, 8, kW2Block, kW2Tile>), \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, kWc2Lds))
+  OLAP_WC2_ATTR(SRC_COLS, false);
+  OLAP_WC2_ATTR(SRC_TUPLES, false);
+  OLAP_WC2_ATTR(SRC_TUPLES, true);
+#undef OLAP_WC2_ATTR
+  const bool wc = ctx->scatter_variant == 0;  // write-combining scatter
   for (int i = 0; i < plan.passes; ++i) {
     const uint32_t fbits = plan.bits[i];
     const uint64_t F = 1ull << fbits;
@@ -877,9 +1049,10 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
     uint2* out = (i == plan.passes - 1) ? final_tuples : ((i & 1) ? tmp1 : tmp0);
     uint64_t blocks, bseg;
     const bool cols = i == 0 && !tuple_in;
+    const bool g2 = wc && pass_uses_geometry2(ctx, fbits);  // 512 threads, 4096-tuple tiles, 2 workgroups per CU
     if (cols) {
       const uint64_t tiles = cs.view.total_units;
-      uint64_t nb = (uint64_t)ctx->compute_units * (wc ? 1 : 2);
+      uint64_t nb = (uint64_t)ctx->compute_units * ((wc && !g2) ? 1 : 2);
       if (nb > tiles) nb = tiles;
       if (nb == 0) nb = 1;
       src.tiles_per_block = (tiles + nb - 1) / nb;
@@ -903,7 +1076,11 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
       if (!so->cnt || !so->dense) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (capacity tables)");
       PhaseScope ps(ctx, PH_PART_SCATTER);
       CapOut co{so->cap, so->cnt, so->dense, d_overflow};
-      if (fbits <= 9 && ctx->line16)
+      if (g2)
+        hipLaunchKernelGGL((k_part_scatter_wc<SRC_TUPLES, true, 8, kW2Block, kW2Tile>), dim3((unsigned)blocks), dim3(kW2Block),
+                           kWc2Lds, ctx->stream, src, shift, fbits, (const uint32_t*)nullptr,
+                           (const uint64_t*)nullptr, out, co);
+      else if (fbits <= 9 && ctx->line16)
         hipLaunchKernelGGL((k_part_scatter_wc<SRC_TUPLES, true, 16>), dim3((unsigned)blocks), dim3(kWBlock),
                            WcLds<16>::kBytes, ctx->stream, src, shift, fbits, (const uint32_t*)nullptr,
                            (const uint64_t*)nullptr, out, co);
@@ -919,7 +1096,11 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
     if (!hist || !seg_out) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (partition pass %d)", i);
     {
       PhaseScope ps(ctx, PH_PART_HIST);
-      if (cols)
+      if (g2 && cols)
+        hipLaunchKernelGGL((k_part_hist<SRC_COLS, kW2Block, kW2Tile>), dim3((unsigned)blocks), dim3(kW2Block), 0, ctx->stream, src, shift, fbits, hist);
+      else if (g2)
+        hipLaunchKernelGGL((k_part_hist<SRC_TUPLES, kW2Block, kW2Tile>), dim3((unsigned)blocks), dim3(kW2Block), 0, ctx->stream, src, shift, fbits, hist);
+      else if (cols)
         hipLaunchKernelGGL((k_part_hist<SRC_COLS, kWBlock>), dim3((unsigned)blocks), dim3(kWBlock), 0, ctx->stream, src, shift, fbits, hist);
       else
         hipLaunchKernelGGL((k_part_hist<SRC_TUPLES, kWBlock>), dim3((unsigned)blocks), dim3(kWBlock), 0, ctx->stream, src, shift, fbits, hist);
@@ -934,7 +1115,15 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
     {
       PhaseScope ps(ctx, PH_PART_SCATTER);
       const bool l16 = fbits <= 9 && ctx->line16;
-      if (wc && cols && l16)
+      if (g2 && cols)
+        hipLaunchKernelGGL((k_part_scatter_wc<SRC_COLS, false, 8, kW2Block, kW2Tile>), dim3((unsigned)blocks), dim3(kW2Block),
+                           kWc2Lds, ctx->stream, src, shift, fbits, (const uint32_t*)hist,
+                           (const uint64_t*)seg_out, out, CapOut{});
+      else if (g2)
+        hipLaunchKernelGGL((k_part_scatter_wc<SRC_TUPLES, false, 8, kW2Block, kW2Tile>), dim3((unsigned)blocks), dim3(kW2Block),
+                           kWc2Lds, ctx->stream, src, shift, fbits, (const uint32_t*)hist,
+                           (const uint64_t*)seg_out, out, CapOut{});
+      else if (wc && cols && l16)
         hipLaunchKernelGGL((k_part_scatter_wc<SRC_COLS, false, 16>), dim3((unsigned)blocks), dim3(kWBlock), WcLds<16>::kBytes,
                            ctx->stream, src, shift, fbits, (const uint32_t*)hist, (const uint64_t*)seg_out, out, CapOut{});
       else if (wc && cols)
@@ -1002,6 +1191,9 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
   if (plan.total_bits + (uint32_t)ctx->hash_skip_bits > 32)
     return ctx->fail(OLAP_ERR_INVALID, "radix bits (%u) + skipped hash bits (%d) exceed 32", plan.total_bits, ctx->hash_skip_bits);
   const uint32_t P = 1u << plan.total_bits;
+  // direct-address LDS table when few enough hash bits remain below the partition bits
+  const uint32_t table_bits = 32u - (uint32_t)ctx->hash_skip_bits - plan.total_bits;
+  const bool direct = ctx->direct_table != 0 && table_bits <= (uint32_t)kDirectBits;
   const uint32_t eb[2] = {4, 4};
   const void* const* lcols[2] = {(const void* const*)lfk, (const void* const*)ly};
   const void* const* rcols[2] = {(const void* const*)rpk, (const void* const*)rx};
@@ -1019,8 +1211,8 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
   OLAP_TRY(pinned_begin(ctx, (lnb + rnb + 2) * 8 * 8 + 8192));
   OLAP_TRY(ws_begin(ctx, need));
   ColumnSet lcs, rcs;
-  if (!in.l_tuples) OLAP_TRY(build_column_set(ctx, lcols, 2, eb, lrows, lnb, in_mem, kPTile, &lcs));
-  if (!in.r_tuples) OLAP_TRY(build_column_set(ctx, rcols, 2, eb, rrows, rnb, in_mem, kPTile, &rcs));
+  if (!in.l_tuples) OLAP_TRY(build_column_set(ctx, lcols, 2, eb, lrows, lnb, in_mem, pass0_tile(ctx, plan), &lcs));
+  if (!in.r_tuples) OLAP_TRY(build_column_set(ctx, rcols, 2, eb, rrows, rnb, in_mem, pass0_tile(ctx, plan), &rcs));
   uint2* tmp0 = plan.passes >= 2 ? (uint2*)ws_alloc(ctx, (maxN + 2) * 8) : nullptr;
   uint2* tmp1 = plan.passes >= 3 ? (uint2*)ws_alloc(ctx, (maxN + 2) * 8) : nullptr;
   uint2* Lt = (uint2*)ws_alloc(ctx, (lt_tuples + 2) * 8);
@@ -1046,8 +1238,16 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
     if (grid > P) grid = P;
     const PartView rv{Rt, rso.off, rso.cnt, rso.dense, rso.cap};
     const PartView lv{Lt, lso.off, lso.cnt, lso.dense, lso.cap};
-    hipLaunchKernelGGL(k_join_probe, dim3((unsigned)grid), dim3(kJBlock), 0, ctx->stream, rv, lv, P, d_fk, d_y, d_x,
-                       (uint32_t)(((((uintptr_t)d_fk) | ((uintptr_t)d_y) | ((uintptr_t)d_x)) & 7) == 0), d_cnt);
+    const uint32_t pair_ok = (uint32_t)(((((uintptr_t)d_fk) | ((uintptr_t)d_y) | ((uintptr_t)d_x)) & 7) == 0);
+    if (direct) {
+      uint64_t dgrid = (uint64_t)ctx->compute_units * 4;
+      if (dgrid > P) dgrid = P;
+      hipLaunchKernelGGL(k_join_probe_direct, dim3((unsigned)dgrid), dim3(kDBlock), 0, ctx->stream, rv, lv, P, table_bits,
+                         d_fk, d_y, d_x, pair_ok, d_cnt);
+    } else {
+      hipLaunchKernelGGL(k_join_probe, dim3((unsigned)grid), dim3(kJBlock), 0, ctx->stream, rv, lv, P, d_fk, d_y, d_x,
+                         pair_ok, d_cnt);
+    }
     OLAP_HIP(ctx, hipGetLastError());
   }
   OLAP_HIP(ctx, hipMemcpyAsync(counters, d_cnt, 40, hipMemcpyDeviceToHost, ctx->stream));
@@ -1063,7 +1263,7 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
     st->passes = plan.passes;
     for (int i = 0; i < 4; ++i) st->radix_bits[i] = plan.bits[i];
     st->nr_partitions = P;
-    st->table_slots = kSlots;
+    st->table_slots = direct ? (1u << table_bits) : (uint32_t)kSlots;
     st->left_rows = NL;
     st->right_rows = NR;
     st->max_build_rows = counters[3];
@@ -1091,6 +1291,10 @@ static int join_run(olap_ctx* ctx, const JoinIn& jin, uint64_t NL, uint64_t NR, 
   } else {
     bits = (uint32_t)ceil_log2_u64((NR + kTargetBuildRows - 1) / kTargetBuildRows);
     if (bits < 1) bits = 1;
+    // Large build sides: stop at the direct-address table's 16 Ki-row partitions (two passes
+    // of <= 512 buckets at 2^32 rows) instead of 4 Ki-row partitions for the probing table.
+    const int dbits = 32 - kDirectBits - ctx->hash_skip_bits;
+    if (ctx->direct_table && dbits >= 1 && dbits < (int)bits && (NR >> dbits) >= 2048) bits = (uint32_t)dbits;
   }
   unsigned long long counters[5] = {0, 0, 0, 0, 0};
   bool allow_capacity = true;
@@ -1124,6 +1328,15 @@ int olap_set_tuning(olap_ctx* ctx, const char* key, int value) {
   if (!std::strcmp(key, "scatter_variant")) {
     if (value < 0 || value > 1) return ctx->fail(OLAP_ERR_INVALID, "scatter_variant must be 0 (write-combining) or 1 (tile-staged)");
     ctx->scatter_variant = value;
+    return OLAP_OK;
+  }
+  if (!std::strcmp(key, "direct_table")) {
+    ctx->direct_table = value != 0;
+    return OLAP_OK;
+  }
+  if (!std::strcmp(key, "wc_geometry")) {
+    if (value != 1 && value != 2) return ctx->fail(OLAP_ERR_INVALID, "wc_geometry must be 1 or 2");
+    ctx->wc_geometry = value;
     return OLAP_OK;
   }
   if (!std::strcmp(key, "line16")) {
@@ -1236,7 +1449,7 @@ static int partition_run(olap_ctx* ctx, const uint32_t* const* key_ptrs, const u
   OLAP_TRY(pinned_begin(ctx, (n_batches + 2) * 8 * 4 + ((uint64_t)nr_partitions + 1) * 8 + 8192));
   OLAP_TRY(ws_begin(ctx, need));
   ColumnSet cs;
-  OLAP_TRY(build_column_set(ctx, cols, ncols, eb, rows, n_batches, in_mem, kPTile, &cs));
+  OLAP_TRY(build_column_set(ctx, cols, ncols, eb, rows, n_batches, in_mem, pass0_tile(ctx, plan), &cs));
   uint2* tmp0 = plan.passes >= 2 ? (uint2*)ws_alloc(ctx, (N + 2) * 8) : nullptr;
   uint2* tmp1 = plan.passes >= 3 ? (uint2*)ws_alloc(ctx, (N + 2) * 8) : nullptr;
   uint2* fin = zipped ? out_tuples : (uint2*)ws_alloc(ctx, (N + 2) * 8);

@@ -17,12 +17,13 @@ kp = capi.ptr_table([fk.data_ptr() + 4 * b * ROWS for b in range(sf)])
 pp = capi.ptr_table([y.data_ptr() + 4 * b * ROWS for b in range(sf)])
 rw = capi.u64_table([ROWS] * sf)
 torch.cuda.synchronize()
-for bits, l16 in ((18, 1), (18, 0), (20, 0), (16, 1), (14, 1)):
+for bits, l16, geo in ((18, 0, 1), (18, 0, 2), (20, 0, 1), (16, 0, 2), (14, 0, 2)):
     ctx.set_tuning("line16", l16)
+    ctx.set_tuning("wc_geometry", geo)
     for rep in range(2):
         ctx.set_profiling(True); ctx.reset_timers()
         offs = ctx.partition_tuples_u32(kp, pp, rw, capi.MEM_DEVICE, 1 << bits, out.data_ptr(), n)
         t = ctx.timers()
     sizes = [offs[i + 1] - offs[i] for i in range(0, 1 << bits, max(1, (1 << bits) // 64))]
-    print(json.dumps({"bits": bits, "line16": l16, "phases": {k: [round(v["ms"], 2), v["launches"]] for k, v in t.items()},
+    print(json.dumps({"bits": bits, "line16": l16, "geometry": geo, "phases": {k: [round(v["ms"], 2), v["launches"]] for k, v in t.items()},
                       "total_rows": offs[-1], "max_sampled_partition": max(sizes)}), flush=True)

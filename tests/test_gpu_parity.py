@@ -315,6 +315,28 @@ def test_partition_variants_vs_oracle_multiset(dev, variant):
         np.testing.assert_array_equal(a, b)
 
 
+@pytest.mark.parametrize("direct", [1, 0])
+@pytest.mark.parametrize("bits", [18, 20, 24])
+def test_join_direct_address_table_vs_probing_table(dev, golden, direct, bits):
+    """With <= 14 hash bits left below the partition bits the build side goes into a
+    collision-free direct-address LDS table (distinct keys have distinct Wang hashes); the
+    probing table must give the same rows.  Includes the keys 0 and 0xFFFFFFFF (case b)."""
+    dev.set_tuning("direct_table", direct)
+    try:
+        for case in ("a", "b"):
+            lf = split_batches(golden[f"join_{case}_fk"], golden[f"join_{case}_left_rows"])
+            ly = split_batches(golden[f"join_{case}_y"], golden[f"join_{case}_left_rows"])
+            rp = split_batches(golden[f"join_{case}_pk"], golden[f"join_{case}_right_rows"])
+            rx = split_batches(golden[f"join_{case}_x"], golden[f"join_{case}_right_rows"])
+            (fk, y, x), stats = _join_sorted(dev, lf, ly, rp, rx, device=True, bits=bits)
+            np.testing.assert_array_equal(fk, golden[f"join_{case}_out_fk"])
+            np.testing.assert_array_equal(y, golden[f"join_{case}_out_y"])
+            np.testing.assert_array_equal(x, golden[f"join_{case}_out_x"])
+            assert stats["table_slots"] == ((1 << (32 - bits)) if direct else 8192)
+    finally:
+        dev.set_tuning("direct_table", 1)
+
+
 def test_join_large_test_shape_vs_oracle(dev):
     """JoinTest.LargeTest: 128 x 64Ki rows per side, generator data; all columns equal after
     sort by (fk, y); row count == left rows."""
@@ -331,7 +353,7 @@ def test_join_large_test_shape_vs_oracle(dev):
     np.testing.assert_array_equal(gfk, ofk)
     np.testing.assert_array_equal(gy, oy)
     np.testing.assert_array_equal(gx, ox)
-    assert stats["passes"] >= 1 and stats["max_build_rows"] <= 6144
+    assert stats["passes"] >= 1 and stats["max_build_rows"] <= max(6144, stats["table_slots"])
 
 
 def test_join_partition_major_output_order(dev):
@@ -491,7 +513,7 @@ def test_join_generator_scale_digest(dev, sf):
     assert out["fk"].rows == n
     got = dev.checksum_rows3_u32(out["fk"].ptr, out["y"].ptr, out["x"].ptr, n)
     assert got == expect
-    assert j.stats["missing_keys"] == 0 and j.stats["max_build_rows"] <= j.stats["table_slots"] * 3 // 4
+    assert j.stats["missing_keys"] == 0 and j.stats["max_build_rows"] <= max(6144, j.stats["table_slots"])
     if sf == 8:  # and the oracle agrees on this size (a few seconds of CPU)
         h = {k: dev.to_host(cols[k]) for k in ("fk", "y", "pk", "x")}
         sp = lambda a: [a[b * rows:(b + 1) * rows] for b in range(sf)]
@@ -553,7 +575,7 @@ def test_multirank_join_loopback_on_one_gpu(dev, world):
         owner = oracle.wang_hash_np(RLk.cpu().numpy().view(np.uint32)) >> np.uint32(32 - bits)
         assert (owner == r).all()
         ofk, oy, ox, stats = ops.join([RLk], [RLp], [RRk], [RRp], bits)
-        assert stats["missing_keys"] == 0 and stats["max_build_rows"] <= 6144
+        assert stats["missing_keys"] == 0 and stats["max_build_rows"] <= max(6144, stats["table_slots"])
         s, xo = dev.checksum_rows3_u32(ofk.data_ptr(), oy.data_ptr(), ox.data_ptr(), ofk.numel())
         tot_sum = (tot_sum + s) & ((1 << 64) - 1)
         tot_xor ^= xo
