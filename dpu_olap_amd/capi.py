@@ -96,7 +96,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("OLAP_GPU_LIB") or LIB_PATH  # OLAP_GPU_LIB: A/B builds in one run
     if not os.path.exists(p):
         raise ImportError(
             f"{p} not found: build the HIP extension first (python -m dpu_olap_amd.build). "

@@ -95,6 +95,9 @@ struct ColsCursor {
   const uint32_t* kp = nullptr;
   const uint32_t* pp = nullptr;
   uint64_t rows = 0, row0 = 0;
+  uint64_t tile = ~0ull;       // last tile located
+  uint64_t local_unit = 0;     // its index inside the batch
+  uint64_t units = 0;          // tiles of the current batch
 };
 
 // Loads one tile: kPTile / BLOCK tuples per thread, valid bits in the returned mask.
@@ -104,13 +107,24 @@ __device__ __forceinline__ uint32_t load_tile(const PassSrc& s, const TileRange&
   constexpr int TPT = TILE / BLOCK;
   uint32_t mask = 0;
   if (SRC == SRC_COLS) {
-    const Loc l = locate(s.v, tile);
+    // tiles are visited in order: step the (batch, local tile) pair instead of locating
+    // every tile afresh (a 64-bit division or a binary search per tile and thread)
+    Loc l;
+    if (tile == cur.tile + 1 && cur.local_unit + 1 < cur.units) {
+      l.batch = cur.batch;
+      l.local_unit = cur.local_unit + 1;
+    } else {
+      l = locate(s.v, tile);
+    }
+    cur.tile = tile;
+    cur.local_unit = l.local_unit;
     if (l.batch != cur.batch) {  // workgroup-uniform
       cur.batch = l.batch;
       cur.kp = (const uint32_t*)s.key_ptrs[l.batch];
       cur.pp = s.pay_ptrs ? (const uint32_t*)s.pay_ptrs[l.batch] : nullptr;
       cur.rows = batch_rows(s.v, l.batch);
       cur.row0 = batch_row0(s.v, l.batch);
+      cur.units = (cur.rows + TILE - 1) / TILE;
     }
     const uint64_t rows = cur.rows;
     const uint64_t r0 = l.local_unit * TILE;
@@ -453,12 +467,21 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_wc(PassSrc s, uint32_t s
   for (uint64_t tile = r.t0; tile < r.t1; ++tile) {
     // (2) bucket + rank of every tuple
     uint32_t br[kWTPT];
+    constexpr uint32_t kFull = (1u << kWTPT) - 1u;
+    if (mask == kFull) {  // whole tile valid (all but the edge tiles): no per-tuple predication
 #pragma unroll
-    for (int i = 0; i < kWTPT; ++i) {
-      br[i] = 0;
-      if (mask & (1u << i)) {
+      for (int i = 0; i < kWTPT; ++i) {
         const uint32_t b = (wang_hash(key[i]) >> shift) & (F - 1);
         br[i] = (b << 16) | atomicAdd(&cl[b], 1u);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < kWTPT; ++i) {
+        br[i] = 0;
+        if (mask & (1u << i)) {
+          const uint32_t b = (wang_hash(key[i]) >> shift) & (F - 1);
+          br[i] = (b << 16) | atomicAdd(&cl[b], 1u);
+        }
       }
     }
     __syncthreads();
@@ -502,9 +525,14 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_wc(PassSrc s, uint32_t s
     }
     __syncthreads();
     // (4) new tuples into the staging area, grouped by bucket, rank order
+    if (mask == kFull) {
 #pragma unroll
-    for (int i = 0; i < kWTPT; ++i) {
-      if (mask & (1u << i)) stage[cl[br[i] >> 16] + (br[i] & 0xFFFFu)] = make_uint2(key[i], pay[i]);
+      for (int i = 0; i < kWTPT; ++i) stage[cl[br[i] >> 16] + (br[i] & 0xFFFFu)] = make_uint2(key[i], pay[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < kWTPT; ++i) {
+        if (mask & (1u << i)) stage[cl[br[i] >> 16] + (br[i] & 0xFFFFu)] = make_uint2(key[i], pay[i]);
+      }
     }
     // next tile's loads fly during the copy-out
     nmask = 0;
