@@ -388,7 +388,7 @@ __global__ __launch_bounds__(kPBlock, 4) void k_part_scatter(PassSrc s, uint32_t
 // (z,w) = 64-bit word: absolute, 8-aligned index of residue slot 0 | residue
 // count << 56 | leading slots that belong to the previous workgroup << 60.
 constexpr int kWBlock = 1024;
-constexpr int kWTPT = kPTile / kWBlock;  // 8
+
 // LINE = tuples per emitted line: 8 (64 B) for up to 1024 buckets, 16 (128 B, a whole L2
 // line; scattered 128-B lines reach ~4.8 TB/s against ~3.6 TB/s for 64-B ones,
 // profiles/r1_ubench_rand_chunk_write.txt) for up to 512 buckets -- the LDS residue buffer
@@ -780,19 +780,22 @@ __global__ __launch_bounds__(kJBlock, 4) void k_join_probe(PartView RV, PartView
 // passes stop at 512 buckets each (two scatter workgroups per CU).
 constexpr int kDirectBits = 14;
 constexpr int kDSlots = 1 << kDirectBits;
-constexpr int kDBlock = 1024;
+constexpr int kDBlock = 512;
 
-__global__ __launch_bounds__(kDBlock) void k_join_probe_direct(PartView RV, PartView LV, uint32_t nparts,
+// The table does not even store keys: inside a partition the slot index IS the key (same
+// top bits + same low bits = same hash = same key), so a slot holds the payload and one
+// occupancy bit.  64 KiB values + 2 KiB bitmap: two workgroups of 512 per CU, and only the
+// bitmap needs clearing between partitions.
+__global__ __launch_bounds__(kDBlock, 4) void k_join_probe_direct(PartView RV, PartView LV, uint32_t nparts,
                                                                uint32_t table_bits, uint32_t* out_fk,
                                                                uint32_t* out_y, uint32_t* out_x,
                                                                uint32_t pair_store_ok, unsigned long long* counters) {
-  __shared__ uint32_t s_keys[kDSlots];
   __shared__ uint32_t s_vals[kDSlots];
-  __shared__ uint32_t s_sp[2];  // the one key equal to the empty marker: {present, value}
+  __shared__ uint32_t s_used[kDSlots / 32];
   const uint2* R = RV.t;
   const uint2* L = LV.t;
   const uint32_t slots = 1u << table_bits, smask = slots - 1;
-  uint32_t my_miss = 0, my_dup = 0, my_clash = 0;
+  uint32_t my_miss = 0, my_dup = 0;
   uint64_t my_max = 0;
   for (uint32_t p = blockIdx.x; p < nparts; p += gridDim.x) {
     const uint64_t rlo = RV.cap ? (uint64_t)p * RV.cap : RV.off[p];
@@ -804,8 +807,7 @@ __global__ __launch_bounds__(kDBlock) void k_join_probe_direct(PartView RV, Part
     const uint32_t pair_store = pair_store_ok && (delta & 1) == 0;
     if (n_r > my_max) my_max = n_r;
     if (n_l == 0) continue;
-    for (uint32_t i = threadIdx.x; i < slots; i += kDBlock) s_keys[i] = kEmpty;
-    if (threadIdx.x == 0) s_sp[0] = 0;
+    for (uint32_t i = threadIdx.x; i < (slots + 31) / 32; i += kDBlock) s_used[i] = 0;
     __syncthreads();
     {  // build
       const uint64_t a = rlo & ~1ull;
@@ -831,16 +833,10 @@ __global__ __launch_bounds__(kDBlock) void k_join_probe_direct(PartView RV, Part
           for (int h = 0; h < 2; ++h) {
             const uint32_t k = h ? v[u].z : v[u].x, val = h ? v[u].w : v[u].y;
             if (i0 + h < rlo || i0 + h >= rhi) continue;
-            if (k == kEmpty) {
-              s_sp[1] = val;
-              if (atomicExch(&s_sp[0], 1u)) ++my_dup;
-            } else {
-              const uint32_t slot = wang_hash(k) & smask;
-              const uint32_t old = atomicExch(&s_keys[slot], k);
-              s_vals[slot] = val;
-              if (old == k) ++my_dup;                 // equal key overwrites (hashtable.c:133)
-              else if (old != kEmpty) ++my_clash;     // impossible for keys of one partition
-            }
+            const uint32_t slot = wang_hash(k) & smask;
+            const uint32_t bit = 1u << (slot & 31);
+            if (atomicOr(&s_used[slot >> 5], bit) & bit) ++my_dup;  // equal key overwrites (hashtable.c:133)
+            s_vals[slot] = val;
           }
         }
       }
@@ -873,15 +869,9 @@ __global__ __launch_bounds__(kDBlock) void k_join_probe_direct(PartView RV, Part
             const uint32_t k = h ? v[u].z : v[u].x;
             ok[h] = i0 + h >= llo && i0 + h < lhi;
             if (!ok[h]) continue;
-            bool hit;
-            if (k == kEmpty) {
-              hit = s_sp[0] != 0;
-              xs[h] = s_sp[1];
-            } else {
-              const uint32_t slot = wang_hash(k) & smask;
-              hit = s_keys[slot] == k;
-              xs[h] = s_vals[slot];
-            }
+            const uint32_t slot = wang_hash(k) & smask;
+            const bool hit = (s_used[slot >> 5] >> (slot & 31)) & 1u;
+            xs[h] = s_vals[slot];
             if (!hit) ++my_miss;
           }
           const uint64_t o = i0 + delta;
@@ -908,11 +898,9 @@ __global__ __launch_bounds__(kDBlock) void k_join_probe_direct(PartView RV, Part
   }
   const uint64_t wm = wave_reduce_add((uint64_t)my_miss);
   const uint64_t wd = wave_reduce_add((uint64_t)my_dup);
-  const uint64_t wc = wave_reduce_add((uint64_t)my_clash);
   if (lane_id() == 0) {
     if (wm) atomicAdd(&counters[0], (unsigned long long)wm);
     if (wd) atomicAdd(&counters[1], (unsigned long long)wd);
-    if (wc) atomicAdd(&counters[2], (unsigned long long)wc);  // reported like a table overflow
   }
   if (threadIdx.x == 0) atomicMax(&counters[3], (unsigned long long)my_max);
 }
@@ -1268,7 +1256,7 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
     const PartView lv{Lt, lso.off, lso.cnt, lso.dense, lso.cap};
     const uint32_t pair_ok = (uint32_t)(((((uintptr_t)d_fk) | ((uintptr_t)d_y) | ((uintptr_t)d_x)) & 7) == 0);
     if (direct) {
-      uint64_t dgrid = (uint64_t)ctx->compute_units * 4;
+      uint64_t dgrid = (uint64_t)ctx->compute_units * 8;
       if (dgrid > P) dgrid = P;
       hipLaunchKernelGGL(k_join_probe_direct, dim3((unsigned)dgrid), dim3(kDBlock), 0, ctx->stream, rv, lv, P, table_bits,
                          d_fk, d_y, d_x, pair_ok, d_cnt);
