@@ -1,0 +1,306 @@
+// bench_harness.cc -- the BM_* benchmarks of the operator hot path on the Google-Benchmark-
+// compatible runner (benchmark/benchmark.h).  Names, ArgNames, argument shapes, counters and
+// the items/bytes accounting are the reference's (host/filter/filter_benchmark.cc,
+// host/take/take_benchmark.cc, host/aggr/aggr_benchmark.cc, host/join/join_benchmark.cc,
+// host/main_benchmark.cc), with *Gpu / "GPUs" in the place of *Dpu / "DPUs":
+//   BM_Filter{Native,Gpu} {Batches = SF<<7, Batch-Size = 64Ki, Threads|GPUs}
+//   BM_Take{Native,Gpu}   {SF, 4Mi, 512Ki, ..} and {SF<<6, 64Ki, 8Ki, ..}   (items = DATA rows)
+//   BM_Sum{Native,Gpu}    {SF, 2Mi, ..} and {SF<<5, 64Ki, ..}
+//   BM_JoinNative         {SF<<5, 64Ki, 64Ki, Partitioned 1|0};  BM_JoinGpu {SF, 2Mi, 2Mi, GPUs}
+// Prepare() runs inside the timed region like in the reference; filter/take/sum force one
+// iteration; {0,...} argument rows free the generated batches between shapes.
+#include <arrow/compute/api.h>
+
+#include <iostream>
+
+#include "batches.h"
+#include "benchmark/benchmark.h"
+#include "olap_host.h"
+#include "operators_gpu.h"
+#include "operators_native.h"
+
+namespace upmemeval {
+namespace {
+
+// One Prepare() + Run() per benchmark iteration; errors end the run the GB way; the
+// operator's timers are accumulated into counters (milliseconds).
+template <class Op, class OnResult>
+void TimedLoop(benchmark::State& state, Op& op, OnResult&& on_result) {
+  for (auto _ : state) {
+    auto prepared = op.Prepare();
+    if (!prepared.ok()) {
+      state.SkipWithError(("Prepare failed with error: " + prepared.ToString()).c_str());
+      return;
+    }
+    auto result = op.Run();
+    if (!result.ok()) {
+      state.SkipWithError(("Run failed with error: " + result.status().ToString()).c_str());
+      return;
+    }
+    on_result(*result);
+    if (auto timers = op.Timers())
+      for (const auto& [name, t] : timers->get())
+        state.counters[name].value += std::chrono::duration<double, std::milli>(t->Result()).count();
+  }
+}
+
+void CountRows(benchmark::State& state, int64_t rows_per_iteration) {
+  const int64_t rows = rows_per_iteration * state.iterations();
+  state.SetItemsProcessed(rows);
+  state.SetBytesProcessed(rows * (int64_t)sizeof(uint32_t));
+}
+
+std::shared_ptr<olap::Device> DeviceOrSkip(benchmark::State& state) {
+  auto dev = olap::Device::Allocate(0);
+  if (!dev.ok()) {
+    state.SkipWithError(dev.status().ToString().c_str());
+    return nullptr;
+  }
+  return *dev;
+}
+
+// Fixture for the single-column benchmarks: range(0) batches of range(1) rows of "v";
+// `threads_arg` is the index of the Threads/GPUs argument; an all-zero row drops the data.
+class ColumnFixture : public benchmark::Fixture {
+ public:
+  explicit ColumnFixture(int threads_arg) : threads_arg_(threads_arg), rng_(42) {}
+
+  void SetUp(benchmark::State& state) override {
+    const int num_batches = (int)state.range(0), batch_size = (int)state.range(1);
+    if (num_batches == 0) {
+      Drop();
+      (void)arrow::SetCpuThreadPoolCapacity(variables::max_threads());
+      state.SkipWithError("not an error :)");
+      return;
+    }
+    if (!arrow::SetCpuThreadPoolCapacity((int)std::max<int64_t>(1, state.range(threads_arg_))).ok())
+      state.SkipWithError("Set CPU threads failed");
+    if (num_batches == (int)batches_.size() && batch_size == batches_.front()->num_rows()) return;
+    schema_ = arrow::schema({arrow::field("v", arrow::uint32(), /*nullable=*/false)});
+    batches_ = generator::MakeRandomRecordBatches(rng_, schema_, num_batches, batch_size);
+    Generated(state);
+    std::cout << "generated " << batches_.size() << " batches of " << batch_size << " rows" << std::endl;
+  }
+
+ protected:
+  virtual void Generated(benchmark::State&) {}
+  virtual void Drop() {
+    schema_.reset();
+    batches_.clear();
+  }
+  bool Skipped(benchmark::State& state) {
+    if (state.range(0) != 0) return false;
+    state.SkipWithError("skip");
+    return true;
+  }
+  int threads_arg_;
+  arrow::random::RandomArrayGenerator rng_;
+  std::shared_ptr<arrow::Schema> schema_;
+  arrow::RecordBatchVector batches_;
+};
+
+// ------------------------------------------------------------------ filter
+class FilterFixture : public ColumnFixture {
+ public:
+  FilterFixture() : ColumnFixture(2) {}
+
+ protected:
+  template <class Op>
+  void Measure(benchmark::State& state, Op& op) {
+    double results = 0;
+    TimedLoop(state, op, [&](uint64_t n) { results += (double)n; });
+    const double processed = (double)state.range(0) * state.range(1) * state.iterations();
+    CountRows(state, state.range(0) * state.range(1));
+    state.counters["Processed (AVG)"] = benchmark::Counter(processed, benchmark::Counter::kAvgIterations);
+    state.counters["Results (AVG)"] = benchmark::Counter(results, benchmark::Counter::kAvgIterations);
+  }
+};
+
+BENCHMARK_DEFINE_F(FilterFixture, BM_FilterNative)(benchmark::State& state) {
+  if (Skipped(state)) return;
+  filter::FilterNative op{schema_, batches_};
+  Measure(state, op);
+}
+BENCHMARK_DEFINE_F(FilterFixture, BM_FilterGpu)(benchmark::State& state) {
+  if (Skipped(state)) return;
+  auto dev = DeviceOrSkip(state);
+  if (!dev) return;
+  filter::FilterGpu op{*dev, batches_};
+  Measure(state, op);
+}
+
+#define OLAP_ONE_SHOT ->MeasureProcessCPUTime()->UseRealTime()->Iterations(1)->Unit(benchmark::kMillisecond)
+
+BENCHMARK_REGISTER_F(FilterFixture, BM_FilterNative)
+    ->ArgNames({"Batches", "Batch-Size", "Threads"})
+    ->Args({variables::scale_factor() << 7, 64 << 10, variables::max_threads_no_ht()})
+    ->Args({0, 0, 0}) OLAP_ONE_SHOT;
+BENCHMARK_REGISTER_F(FilterFixture, BM_FilterGpu)
+    ->ArgNames({"Batches", "Batch-Size", "GPUs"})
+    ->Args({variables::scale_factor() << 7, 64 << 10, variables::max_gpus()})
+    ->Args({0, 0, 0}) OLAP_ONE_SHOT;
+
+// --------------------------------------------------------------------- sum
+class SumFixture : public ColumnFixture {
+ public:
+  SumFixture() : ColumnFixture(2) {}
+
+ protected:
+  template <class Op>
+  void Measure(benchmark::State& state, Op& op) {
+    double total = 0;
+    TimedLoop(state, op, [&](uint64_t s) { total += (double)s; });
+    CountRows(state, state.range(0) * state.range(1));
+    state.counters["Result"] = benchmark::Counter(total, benchmark::Counter::kAvgIterations);
+  }
+};
+
+BENCHMARK_DEFINE_F(SumFixture, BM_SumNative)(benchmark::State& state) {
+  if (Skipped(state)) return;
+  aggr::AggrNative<arrow::UInt64Array> op{schema_, batches_, "sum"};
+  Measure(state, op);
+}
+BENCHMARK_DEFINE_F(SumFixture, BM_SumGpu)(benchmark::State& state) {
+  if (Skipped(state)) return;
+  auto dev = DeviceOrSkip(state);
+  if (!dev) return;
+  aggr::SumGpu op{*dev, batches_};
+  Measure(state, op);
+}
+
+BENCHMARK_REGISTER_F(SumFixture, BM_SumNative)
+    ->ArgNames({"Batches", "Batch-Size", "Threads"})
+    ->ArgsProduct({{variables::scale_factor()}, {2 << 20}, {variables::max_threads_no_ht(), variables::max_threads()}})
+    ->Args({0, 0, 0})
+    ->ArgsProduct({{variables::scale_factor() << 5}, {64 << 10}, {variables::max_threads_no_ht(), variables::max_threads()}})
+    ->Args({0, 0, 0}) OLAP_ONE_SHOT;
+BENCHMARK_REGISTER_F(SumFixture, BM_SumGpu)
+    ->ArgNames({"Batches", "Batch-Size", "GPUs"})
+    ->Args({variables::scale_factor(), 2 << 20, variables::max_gpus()})
+    ->Args({0, 0, 0})
+    ->Args({variables::scale_factor() << 5, 64 << 10, variables::max_gpus()})
+    ->Args({0, 0, 0}) OLAP_ONE_SHOT;
+
+// -------------------------------------------------------------------- take
+class TakeFixture : public ColumnFixture {
+ public:
+  TakeFixture() : ColumnFixture(3) {}
+
+ protected:
+  void Generated(benchmark::State& state) override {  // range(2) indices per batch, uniform over the batch's rows
+    auto bounds = arrow::key_value_metadata({"min", "max"}, {"0", std::to_string(state.range(1) - 1)});
+    auto index_schema = arrow::schema({arrow::field("i", arrow::uint32(), false, bounds)});
+    indices_ = generator::MakeRandomRecordBatches(rng_, index_schema, (int)state.range(0), (int)state.range(2));
+  }
+  void Drop() override {
+    ColumnFixture::Drop();
+    indices_.clear();
+  }
+  template <class Op>
+  void Measure(benchmark::State& state, Op& op) {
+    TimedLoop(state, op, [](const std::shared_ptr<arrow::Table>&) {});
+    CountRows(state, state.range(0) * state.range(1));  // the reference counts the DATA rows
+  }
+  arrow::RecordBatchVector indices_;
+};
+
+BENCHMARK_DEFINE_F(TakeFixture, BM_TakeNative)(benchmark::State& state) {
+  if (Skipped(state)) return;
+  take::TakeNative op{schema_, batches_, indices_};
+  Measure(state, op);
+}
+BENCHMARK_DEFINE_F(TakeFixture, BM_TakeGpu)(benchmark::State& state) {
+  if (Skipped(state)) return;
+  auto dev = DeviceOrSkip(state);
+  if (!dev) return;
+  take::TakeGpu op{*dev, batches_, indices_};
+  Measure(state, op);
+}
+
+BENCHMARK_REGISTER_F(TakeFixture, BM_TakeNative)
+    ->ArgNames({"Batches", "Batch-Size", "Indices-Batch-Size", "Threads"})
+    ->ArgsProduct({{variables::scale_factor()}, {4 << 20}, {512 << 10}, {variables::max_threads_no_ht(), variables::max_threads()}})
+    ->Args({0, 0, 0, 0})
+    ->ArgsProduct({{variables::scale_factor() << 6}, {64 << 10}, {8 << 10}, {variables::max_threads_no_ht(), variables::max_threads()}})
+    ->Args({0, 0, 0, 0}) OLAP_ONE_SHOT;
+BENCHMARK_REGISTER_F(TakeFixture, BM_TakeGpu)
+    ->ArgNames({"Batches", "Batch-Size", "Indices-Batch-Size", "GPUs"})
+    ->Args({variables::scale_factor(), 4 << 20, 512 << 10, variables::max_gpus()})
+    ->Args({0, 0, 0, 0})
+    ->Args({variables::scale_factor() << 6, 64 << 10, 8 << 10, variables::max_gpus()})
+    ->Args({0, 0, 0, 0}) OLAP_ONE_SHOT;
+
+// -------------------------------------------------------------------- join
+// right {pk = 0,1,2,.., x random}, left {fk in the matching batch's key range, y random}
+class JoinFixture : public benchmark::Fixture {
+ public:
+  JoinFixture() : rng_(42) {}
+
+  void SetUp(benchmark::State& state) override {
+    const int num_batches = (int)state.range(0), left_rows = (int)state.range(1), right_rows = (int)state.range(2);
+    if ((int)right_.size() != num_batches || right_.front()->num_rows() != right_rows) {
+      auto payload = generator::MakeRandomRecordBatches(rng_, arrow::schema({arrow::field("x", arrow::uint32(), false)}), num_batches, right_rows);
+      right_ = generator::AddColumn("pk", payload, generator::MakeIndexColumn(num_batches, right_rows).ValueOrDie());
+    }
+    if ((int)left_.size() != num_batches || left_.front()->num_rows() != left_rows) {
+      auto payload = generator::MakeRandomRecordBatches(rng_, arrow::schema({arrow::field("y", arrow::uint32(), false)}), num_batches, left_rows);
+      left_ = generator::AddColumn("fk", payload, generator::MakeForeignKeyColumn(rng_, right_rows, num_batches, left_rows).ValueOrDie());
+    }
+    std::cout << left_.size() << " left / " << right_.size() << " right batches generated" << std::endl;
+  }
+  void TearDown(benchmark::State&) override {
+    left_.clear();
+    right_.clear();
+  }
+
+ protected:
+  // rows x columns over both tables, x 4 bytes; NOT multiplied by the iteration count
+  // (the reference's accounting, join_benchmark.cc:114-125,141-142)
+  template <class Op>
+  void Measure(benchmark::State& state, Op& op) {
+    const int64_t items = (int64_t)left_.size() * left_.front()->num_rows() * left_.front()->num_columns() +
+                          (int64_t)right_.size() * right_.front()->num_rows() * right_.front()->num_columns();
+    uint64_t rows = 0;
+    TimedLoop(state, op, [&](const std::shared_ptr<arrow::Table>& t) { rows += (uint64_t)t->num_rows(); });
+    std::cout << "Total Rows: " << rows << " Iterations: " << state.iterations() << std::endl;
+    state.SetItemsProcessed(items);
+    state.SetBytesProcessed(items * (int64_t)sizeof(uint32_t));
+  }
+  arrow::random::RandomArrayGenerator rng_;
+  arrow::RecordBatchVector left_, right_;
+};
+
+BENCHMARK_DEFINE_F(JoinFixture, BM_JoinNative)(benchmark::State& state) {
+  join::JoinNative op{left_.front()->schema(), right_.front()->schema(), left_, right_, state.range(3) != 0};
+  Measure(state, op);
+}
+BENCHMARK_DEFINE_F(JoinFixture, BM_JoinGpu)(benchmark::State& state) {
+  auto dev = DeviceOrSkip(state);
+  if (!dev) return;
+  join::JoinGpu op{*dev, left_.front()->schema(), right_.front()->schema(), left_, right_};
+  Measure(state, op);
+}
+
+BENCHMARK_REGISTER_F(JoinFixture, BM_JoinNative)
+    ->ArgNames({"Batches", "L-Batch-Size", "R-Batch-Size", "Partitioned"})
+    ->Args({variables::scale_factor() << 5, 64 << 10, 64 << 10, 1})
+    ->Args({variables::scale_factor() << 5, 64 << 10, 64 << 10, 0})
+    ->MeasureProcessCPUTime()->UseRealTime()->Unit(benchmark::kMillisecond);
+BENCHMARK_REGISTER_F(JoinFixture, BM_JoinGpu)
+    ->ArgNames({"Batches", "L-Batch-Size", "R-Batch-Size", "GPUs"})
+    ->Args({variables::scale_factor(), 2 << 20, 2 << 20, variables::max_gpus()})
+    ->MeasureProcessCPUTime()->UseRealTime()->Unit(benchmark::kMillisecond);
+
+}  // namespace
+}  // namespace upmemeval
+
+int main(int argc, char** argv) {
+  if (!arrow::compute::Initialize().ok()) return 2;
+  benchmark::AddCustomContext("NR_GPUS", std::to_string(variables::max_gpus()));
+  benchmark::AddCustomContext("SF", std::to_string(variables::scale_factor()));
+  benchmark::Initialize(&argc, argv);
+  if (benchmark::ReportUnrecognizedArguments(argc, argv)) return 1;
+  benchmark::RunSpecifiedBenchmarks();
+  benchmark::Shutdown();
+  return 0;
+}

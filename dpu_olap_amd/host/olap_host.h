@@ -1,0 +1,194 @@
+// olap_host.h -- everything the C++ host side shares: run-time configuration, the named
+// timers the operators export, the RAII device context over the C ABI (include/olap_gpu.h)
+// and the Arrow <-> pointer-table glue.
+//
+// Roles in the reference: host/system/system.h (env configuration), host/timer/timer.h
+// (timer::Timers, the return type of every operator's Timers()), host/dpuext/dpuext.hpp
+// (dpu::DpuSet), host/dpuext/arrow_utils.{h,cc} (Arrow buffers <-> device) and
+// host/dpuext/status.h (error -> arrow::Status).
+#pragma once
+
+#include <arrow/api.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdlib>
+#include <map>
+#include <memory>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "olap_gpu.h"
+
+// ---------------------------------------------------------------- configuration
+namespace variables {
+
+inline int from_env(const char* name, int fallback) {
+  const char* v = std::getenv(name);
+  return (v && *v) ? std::atoi(v) : fallback;
+}
+// NR_GPUS plays the part of the reference's NR_DPUS; SF is the scale factor of the BM_*
+// argument shapes; MAX_THREADS caps the Arrow CPU pool of the *Native operators.
+inline int max_gpus() { return from_env("NR_GPUS", 1); }
+inline int scale_factor() { return from_env("SF", 4); }
+inline int max_threads() { return from_env("MAX_THREADS", (int)std::thread::hardware_concurrency()); }
+inline int max_threads_no_ht() { return from_env("MAX_THREADS", std::max(1, (int)std::thread::hardware_concurrency() / 2)); }
+
+}  // namespace variables
+
+// ------------------------------------------------------------------------ timers
+namespace timer {
+
+// One accumulating stopwatch per rank (= GPU).  Device phases come from the library's
+// HIP-event timers and are added with Add().
+class Timer {
+  using clock = std::chrono::steady_clock;
+
+ public:
+  explicit Timer(uint32_t ranks) : acc_(std::max(1u, ranks)), t0_(std::max(1u, ranks)) {}
+  void Start(uint32_t rank = 0) { t0_.at(rank) = clock::now(); }
+  void Stop(uint32_t rank = 0) { acc_.at(rank) += std::chrono::duration_cast<std::chrono::nanoseconds>(clock::now() - t0_.at(rank)); }
+  void Add(std::chrono::nanoseconds d, uint32_t rank = 0) { acc_.at(rank) += d; }
+  std::chrono::nanoseconds Result() const {
+    std::chrono::nanoseconds sum{0};
+    for (const auto& d : acc_) sum += d;
+    return sum;
+  }
+
+ private:
+  std::vector<std::chrono::nanoseconds> acc_;
+  std::vector<clock::time_point> t0_;
+};
+
+class Timers {
+ public:
+  explicit Timers(uint32_t ranks) : ranks_(ranks) {}
+  std::shared_ptr<Timer> New(const std::string& name) { return by_name_[name] = std::make_shared<Timer>(ranks_); }
+  std::shared_ptr<Timer> Get(const std::string& name) {
+    auto it = by_name_.find(name);
+    return it != by_name_.end() ? it->second : New(name);
+  }
+  const std::map<std::string, std::shared_ptr<Timer>>& get() const { return by_name_; }
+
+ private:
+  uint32_t ranks_;
+  std::map<std::string, std::shared_ptr<Timer>> by_name_;
+};
+
+}  // namespace timer
+
+// ------------------------------------------------------------------------ device
+namespace olap {
+
+class Device {
+ public:
+  static arrow::Result<std::shared_ptr<Device>> Allocate(int device_id = 0) {
+    olap_ctx* ctx = nullptr;
+    const int rc = olap_create(device_id, &ctx);
+    if (rc != OLAP_OK) return arrow::Status::UnknownError("olap_create failed with code ", rc, " (no usable HIP device?)");
+    return std::shared_ptr<Device>(new Device(ctx));
+  }
+  ~Device() { olap_destroy(ctx_); }
+  Device(const Device&) = delete;
+  Device& operator=(const Device&) = delete;
+
+  olap_ctx* ctx() const { return ctx_; }
+  uint32_t nr_ranks() const { return 1; }
+
+  arrow::Status Check(int rc) const {
+    return rc == OLAP_OK ? arrow::Status::OK() : arrow::Status::UnknownError("olap error ", rc, ": ", olap_last_error(ctx_));
+  }
+
+  // Prepare() of every operator: HIP-event timers on, counters cleared.
+  arrow::Status BeginTimers() const {
+    ARROW_RETURN_NOT_OK(Check(olap_set_profiling(ctx_, 1)));
+    return Check(olap_reset_timers(ctx_));
+  }
+
+  // Library phases -> timers: one entry per phase, plus "gpu-work" = everything but the
+  // copies (the reference's dpu-work next to copy-to-dpu / copy-from-dpu).
+  arrow::Status FoldTimers(timer::Timers* timers) const {
+    const char* names[32];
+    double ms[32];
+    uint64_t launches[32];
+    int n = 0;
+    ARROW_RETURN_NOT_OK(Check(olap_get_timers(ctx_, names, ms, launches, 32, &n)));
+    double work_ms = 0;
+    for (int i = 0; i < std::min(n, 32); ++i) {
+      const std::string name = names[i];
+      timers->Get(name)->Add(std::chrono::nanoseconds((int64_t)(ms[i] * 1e6)));
+      if (name != "copy-to-gpu" && name != "copy-from-gpu") work_ms += ms[i];
+    }
+    timers->Get("gpu-work")->Add(std::chrono::nanoseconds((int64_t)(work_ms * 1e6)));
+    return arrow::Status::OK();
+  }
+
+ private:
+  explicit Device(olap_ctx* ctx) : ctx_(ctx) {}
+  olap_ctx* ctx_;
+};
+
+// (pointer, rows) tables of one column across batches -- the ABI's view of a
+// RecordBatchVector.  Data buffer only (buffers[1]), slice offsets honoured, no nulls.
+struct ColumnTable {
+  std::vector<const void*> ptrs;
+  std::vector<uint64_t> rows;
+  uint64_t total_rows() const {
+    uint64_t n = 0;
+    for (auto r : rows) n += r;
+    return n;
+  }
+};
+
+inline arrow::Result<ColumnTable> MakeColumnTable(const arrow::RecordBatchVector& batches, int column) {
+  ColumnTable t;
+  for (const auto& batch : batches) {
+    if (column < 0 || column >= batch->num_columns()) return arrow::Status::Invalid("column index out of range");
+    const auto& d = batch->column_data(column);
+    const auto* fixed = dynamic_cast<const arrow::FixedWidthType*>(d->type.get());
+    if (!fixed || d->buffers.size() < 2) return arrow::Status::TypeError("fixed-width column expected");
+    if (d->GetNullCount() != 0) return arrow::Status::NotImplemented("nullable columns are outside the hot path");
+    const int64_t width = fixed->bit_width() / 8;
+    const uint8_t* base = d->buffers[1] ? d->buffers[1]->data() : nullptr;
+    t.ptrs.push_back(base ? base + d->offset * width : nullptr);
+    t.rows.push_back((uint64_t)d->length);
+  }
+  return t;
+}
+
+inline arrow::Result<int> DtypeOf(const arrow::DataType& type) {
+  switch (type.id()) {
+    case arrow::Type::UINT32: return (int)OLAP_U32;
+    case arrow::Type::INT32: return (int)OLAP_I32;
+    case arrow::Type::UINT64: return (int)OLAP_U64;
+    case arrow::Type::INT64: return (int)OLAP_I64;
+    default: return arrow::Status::TypeError("the GPU hot path covers uint32/int32/uint64/int64, got ", type.ToString());
+  }
+}
+
+inline int WidthOf(int dtype) { return (dtype == OLAP_U32 || dtype == OLAP_I32) ? 4 : 8; }
+
+// A filled host buffer as an arrow::Array (no validity bitmap).
+inline std::shared_ptr<arrow::Array> WrapBuffer(const std::shared_ptr<arrow::DataType>& type, int64_t length,
+                                                std::shared_ptr<arrow::Buffer> buffer) {
+  return arrow::MakeArray(arrow::ArrayData::Make(type, length, {nullptr, std::move(buffer)}));
+}
+
+// n output buffers sized for rows[b] elements each, plus the raw pointer table.
+struct OutputBuffers {
+  std::vector<std::shared_ptr<arrow::Buffer>> buffers;
+  std::vector<void*> ptrs;
+};
+
+inline arrow::Result<OutputBuffers> AllocateOutputs(const std::vector<uint64_t>& rows, int width) {
+  OutputBuffers out;
+  for (uint64_t r : rows) {
+    ARROW_ASSIGN_OR_RAISE(auto buf, arrow::AllocateBuffer((int64_t)std::max<uint64_t>(r, 1) * width));
+    out.ptrs.push_back(buf->mutable_data());
+    out.buffers.push_back(std::move(buf));
+  }
+  return out;
+}
+
+}  // namespace olap

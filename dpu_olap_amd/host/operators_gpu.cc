@@ -1,0 +1,184 @@
+#include "operators_gpu.h"
+
+namespace upmemeval {
+
+using olap::ColumnTable;
+
+// ------------------------------------------------------------------ filter
+namespace filter {
+
+arrow::Result<std::shared_ptr<arrow::ChunkedArray>> FilterGpu::GetResult() {
+  ARROW_RETURN_NOT_OK(Prepared());
+  if (batches_.empty()) return arrow::ChunkedArray::Make({}, arrow::uint32());
+  const auto type = batches_.front()->column(0)->type();
+  ARROW_ASSIGN_OR_RAISE(const int dtype, olap::DtypeOf(*type));
+  ARROW_ASSIGN_OR_RAISE(ColumnTable in, olap::MakeColumnTable(batches_, 0));
+  // worst-case room per batch: a batch may pass entirely
+  ARROW_ASSIGN_OR_RAISE(auto out, olap::AllocateOutputs(in.rows, olap::WidthOf(dtype)));
+  std::vector<uint64_t> kept(in.rows.size());
+  const uint64_t threshold = 1ull << 30;  // the low bytes serve the 32-bit types too
+  ARROW_RETURN_NOT_OK(system_.Check(olap_filter_lt(system_.ctx(), dtype, in.ptrs.data(), in.rows.data(), in.ptrs.size(),
+                                                   OLAP_MEM_HOST, &threshold, out.ptrs.data(), OLAP_MEM_HOST, kept.data(),
+                                                   nullptr)));
+  auto build = timers_->New("build-result");
+  build->Start();
+  arrow::ArrayVector chunks;
+  for (size_t b = 0; b < kept.size(); ++b) chunks.push_back(olap::WrapBuffer(type, (int64_t)kept[b], out.buffers[b]));
+  build->Stop();
+  ARROW_RETURN_NOT_OK(Finish());
+  return arrow::ChunkedArray::Make(chunks, type);
+}
+
+arrow::Result<uint64_t> FilterGpu::Run() {
+  ARROW_ASSIGN_OR_RAISE(auto chunks, GetResult());
+  return (uint64_t)chunks->length();
+}
+
+}  // namespace filter
+
+// -------------------------------------------------------------------- take
+namespace take {
+
+arrow::Result<std::shared_ptr<arrow::Table>> TakeGpu::Run() {
+  ARROW_RETURN_NOT_OK(Prepared());
+  if (batches_.empty() || batches_.size() != indices_batches_.size())
+    return arrow::Status::Invalid("one index batch per data batch expected");
+  const auto type = batches_.front()->column(0)->type();
+  ARROW_ASSIGN_OR_RAISE(const int dtype, olap::DtypeOf(*type));
+  if (indices_batches_.front()->column(0)->type_id() != arrow::Type::UINT32)
+    return arrow::Status::TypeError("uint32 selection indices expected");
+  ARROW_ASSIGN_OR_RAISE(ColumnTable data, olap::MakeColumnTable(batches_, 0));
+  ARROW_ASSIGN_OR_RAISE(ColumnTable idx, olap::MakeColumnTable(indices_batches_, 0));
+  ARROW_ASSIGN_OR_RAISE(auto out, olap::AllocateOutputs(idx.rows, olap::WidthOf(dtype)));
+  ARROW_RETURN_NOT_OK(system_.Check(olap_take(system_.ctx(), dtype, data.ptrs.data(), data.rows.data(),
+                                              reinterpret_cast<const uint32_t* const*>(idx.ptrs.data()), idx.rows.data(),
+                                              data.ptrs.size(), OLAP_MEM_HOST, out.ptrs.data(), OLAP_MEM_HOST)));
+  arrow::RecordBatchVector result;
+  for (size_t b = 0; b < idx.rows.size(); ++b) {
+    auto column = olap::WrapBuffer(type, (int64_t)idx.rows[b], out.buffers[b]);
+    result.push_back(arrow::RecordBatch::Make(batches_.front()->schema(), column->length(), {column}));
+  }
+  ARROW_RETURN_NOT_OK(Finish());
+  return arrow::Table::FromRecordBatches(result);
+}
+
+}  // namespace take
+
+// --------------------------------------------------------------------- sum
+namespace aggr {
+
+arrow::Result<uint64_t> SumGpu::Run() {
+  ARROW_RETURN_NOT_OK(Prepared());
+  uint64_t sum = 0;
+  if (!batches_.empty()) {
+    ARROW_ASSIGN_OR_RAISE(const int dtype, olap::DtypeOf(*batches_.front()->column(0)->type()));
+    ARROW_ASSIGN_OR_RAISE(ColumnTable in, olap::MakeColumnTable(batches_, 0));
+    ARROW_RETURN_NOT_OK(system_.Check(
+        olap_sum(system_.ctx(), dtype, in.ptrs.data(), in.rows.data(), in.ptrs.size(), OLAP_MEM_HOST, &sum)));
+  }
+  ARROW_RETURN_NOT_OK(Finish());
+  return sum;
+}
+
+}  // namespace aggr
+
+// --------------------------------------------------------------- partition
+namespace partition {
+
+// Keys are partitioned together with their global row index (the reference's
+// selection_indices_vector); the other columns follow by a GPU gather with those row ids,
+// which is what Partitioner::TakeKernel does on the DPUs.
+arrow::Result<arrow::RecordBatchVector> PartitionGpu::Run() {
+  ARROW_RETURN_NOT_OK(Prepared());
+  const int key = schema_->GetFieldIndex(key_column_);
+  if (key < 0) return arrow::Status::Invalid("no column named ", key_column_);
+  ARROW_ASSIGN_OR_RAISE(ColumnTable keys, olap::MakeColumnTable(batches_, key));
+  const uint64_t n = keys.total_rows();
+  ARROW_ASSIGN_OR_RAISE(auto part, olap::AllocateOutputs({n, n}, 4));  // [0] keys, [1] row ids
+  std::vector<uint64_t> offsets(nr_partitions_ + 1);
+  ARROW_RETURN_NOT_OK(system_.Check(olap_partition_u32(
+      system_.ctx(), reinterpret_cast<const uint32_t* const*>(keys.ptrs.data()), nullptr, keys.rows.data(),
+      keys.ptrs.size(), OLAP_MEM_HOST, nr_partitions_, static_cast<uint32_t*>(part.ptrs[0]),
+      static_cast<uint32_t*>(part.ptrs[1]), n, OLAP_MEM_HOST, offsets.data())));
+  ARROW_ASSIGN_OR_RAISE(auto table, arrow::Table::FromRecordBatches(schema_, batches_));
+  arrow::ArrayVector columns(schema_->num_fields());
+  for (int c = 0; c < schema_->num_fields(); ++c) {
+    if (c == key) {
+      columns[c] = olap::WrapBuffer(arrow::uint32(), (int64_t)n, part.buffers[0]);
+      continue;
+    }
+    ARROW_ASSIGN_OR_RAISE(const int dtype, olap::DtypeOf(*schema_->field(c)->type()));
+    // the column as one contiguous buffer (a host copy, not a computation), gathered on the GPU
+    std::shared_ptr<arrow::Array> flat;
+    if (table->column(c)->num_chunks() == 1) {
+      flat = table->column(c)->chunk(0);
+    } else if (table->column(c)->num_chunks() == 0) {
+      ARROW_ASSIGN_OR_RAISE(flat, arrow::MakeEmptyArray(schema_->field(c)->type()));
+    } else {
+      ARROW_ASSIGN_OR_RAISE(flat, arrow::Concatenate(table->column(c)->chunks()));
+    }
+    ARROW_ASSIGN_OR_RAISE(auto gathered, olap::AllocateOutputs({n}, olap::WidthOf(dtype)));
+    if (n) {
+      const void* data = flat->data()->buffers[1]->data() + flat->data()->offset * olap::WidthOf(dtype);
+      const uint32_t* ids = static_cast<const uint32_t*>(part.ptrs[1]);
+      const uint64_t data_rows = (uint64_t)flat->length();
+      ARROW_RETURN_NOT_OK(system_.Check(olap_take(system_.ctx(), dtype, &data, &data_rows, &ids, &n, 1, OLAP_MEM_HOST,
+                                                  gathered.ptrs.data(), OLAP_MEM_HOST)));
+    }
+    columns[c] = olap::WrapBuffer(schema_->field(c)->type(), (int64_t)n, gathered.buffers[0]);
+  }
+  arrow::RecordBatchVector result;
+  for (uint32_t p = 0; p < nr_partitions_; ++p) {
+    const int64_t begin = (int64_t)offsets[p], length = (int64_t)(offsets[p + 1] - offsets[p]);
+    arrow::ArrayVector slice;
+    for (const auto& column : columns) slice.push_back(column->Slice(begin, length));
+    result.push_back(arrow::RecordBatch::Make(schema_, length, slice));
+  }
+  ARROW_RETURN_NOT_OK(Finish());
+  return result;
+}
+
+}  // namespace partition
+
+// -------------------------------------------------------------------- join
+namespace join {
+
+arrow::Result<std::shared_ptr<arrow::Table>> JoinGpu::Run() {
+  ARROW_RETURN_NOT_OK(Prepared());
+  auto outer = timers_->New("outer");
+  outer->Start();
+  const int fk = left_schema_->GetFieldIndex("fk"), pk = right_schema_->GetFieldIndex("pk");
+  if (fk < 0 || pk < 0) return arrow::Status::Invalid("left table needs a column 'fk', right table a column 'pk'");
+  // one 32-bit payload per side travels with the key (the benchmark schema {fk,y} x {pk,x})
+  if (left_schema_->num_fields() != 2 || right_schema_->num_fields() != 2)
+    return arrow::Status::NotImplemented("exactly one payload column per side");
+  const int ly = 1 - fk, rx = 1 - pk;
+  for (const auto& field : {left_schema_->field(fk), left_schema_->field(ly), right_schema_->field(pk), right_schema_->field(rx)})
+    if (field->type()->id() != arrow::Type::UINT32 && field->type()->id() != arrow::Type::INT32)
+      return arrow::Status::TypeError("32-bit integer join columns expected, got ", field->ToString());
+  ARROW_ASSIGN_OR_RAISE(ColumnTable lkey, olap::MakeColumnTable(left_batches_, fk));
+  ARROW_ASSIGN_OR_RAISE(ColumnTable lpay, olap::MakeColumnTable(left_batches_, ly));
+  ARROW_ASSIGN_OR_RAISE(ColumnTable rkey, olap::MakeColumnTable(right_batches_, pk));
+  ARROW_ASSIGN_OR_RAISE(ColumnTable rpay, olap::MakeColumnTable(right_batches_, rx));
+  const uint64_t n_left = lkey.total_rows();
+  ARROW_ASSIGN_OR_RAISE(auto out, olap::AllocateOutputs({n_left, n_left, n_left}, 4));  // fk, y, x
+  auto u32pp = [](const ColumnTable& t) { return reinterpret_cast<const uint32_t* const*>(t.ptrs.data()); };
+  uint64_t out_rows = 0;
+  ARROW_RETURN_NOT_OK(system_.Check(olap_join_u32(
+      system_.ctx(), u32pp(lkey), u32pp(lpay), lkey.rows.data(), lkey.ptrs.size(), u32pp(rkey), u32pp(rpay),
+      rkey.rows.data(), rkey.ptrs.size(), OLAP_MEM_HOST, static_cast<uint32_t*>(out.ptrs[0]),
+      static_cast<uint32_t*>(out.ptrs[1]), static_cast<uint32_t*>(out.ptrs[2]), n_left, OLAP_MEM_HOST, &out_rows, &stats_)));
+  arrow::FieldVector fields = left_schema_->fields();
+  fields.push_back(right_schema_->field(rx));
+  std::vector<std::shared_ptr<arrow::Array>> columns(3);
+  columns[fk] = olap::WrapBuffer(left_schema_->field(fk)->type(), (int64_t)out_rows, out.buffers[0]);
+  columns[ly] = olap::WrapBuffer(left_schema_->field(ly)->type(), (int64_t)out_rows, out.buffers[1]);
+  columns[2] = olap::WrapBuffer(right_schema_->field(rx)->type(), (int64_t)out_rows, out.buffers[2]);
+  outer->Stop();
+  ARROW_RETURN_NOT_OK(Finish());
+  return arrow::Table::Make(arrow::schema(fields), columns);
+}
+
+}  // namespace join
+
+}  // namespace upmemeval

@@ -34,7 +34,7 @@ def test_native_operators_and_registry(host_build):
     for name in ("FilterTest.SimpleTest", "FilterTest.ResultTest", "FilterTest.LongerTest", "TakeTest.LargeTest",
                  "SumTest.LargeTest", "JoinTest.SimpleTest", "JoinTest.LargeTest", "PartitionTest.SimpleTest",
                  "PartitionTest.LargeTest"):
-        assert name in lst  # the reference's test cases, host/*/*_test.cc
+        assert name in lst  # the reference's test cases
     env = dict(os.environ, SF="2", NR_GPUS="1")
     names = subprocess.run([BENCH, "--benchmark_list_tests"], capture_output=True, text=True, env=env, timeout=60).stdout
     for frag in ("BM_FilterNative/Batches:256/Batch-Size:65536/Threads:", "BM_FilterGpu/Batches:256/Batch-Size:65536/GPUs:1",
