@@ -28,7 +28,7 @@ EXPORTS = [
     "olap_set_stream", "olap_get_stream", "olap_synchronize", "olap_reserve_workspace",
     "olap_workspace_bytes", "olap_malloc", "olap_free", "olap_memcpy_h2d", "olap_memcpy_d2h",
     "olap_memset", "olap_set_profiling", "olap_reset_timers", "olap_get_timers", "olap_filter_lt",
-    "olap_sum", "olap_take", "olap_partition_u32", "olap_partition_tuples_u32", "olap_join_u32", "olap_join_tuples_u32", "olap_join_configure", "olap_join_set_hash_skip_bits", "olap_set_tuning",
+    "olap_sum", "olap_take", "olap_partition_u32", "olap_partition_tuples_u32", "olap_join_u32", "olap_join_tuples_u32", "olap_join_presplit_u32", "olap_join_configure", "olap_join_set_hash_skip_bits", "olap_set_tuning",
     "olap_gen_uniform_u32", "olap_gen_uniform_u64", "olap_gen_index_u32", "olap_gen_fk_u32",
     "olap_gen_uniform_u32_at", "olap_checksum", "olap_checksum_rows3_u32",
 ]
@@ -133,6 +133,8 @@ def load_library(path: str | None = None) -> C.CDLL:
                               C.POINTER(JoinStats)]),
         "olap_partition_tuples_u32": (i, [vp, pvp, pvp, pu64, u64, i, u32, vp, u64, pu64]),
         "olap_join_tuples_u32": (i, [vp, vp, u64, vp, u64, vp, vp, vp, u64, pu64, C.POINTER(JoinStats)]),
+        "olap_join_presplit_u32": (i, [vp, vp, u64, pu64, pu64, vp, u64, pu64, pu64, u32, u32, vp, vp, vp, u64, pu64,
+                                       C.POINTER(JoinStats)]),
         "olap_join_configure": (i, [vp, i, i]),
         "olap_join_set_hash_skip_bits": (i, [vp, i]),
         "olap_set_tuning": (i, [vp, C.c_char_p, i]),
@@ -315,6 +317,19 @@ class Context:
         st = JoinStats()
         self._check(self.lib.olap_join_tuples_u32(self.h, left_tuples, n_left, right_tuples, n_right, out_fk, out_y,
                                                   out_x, out_capacity, C.byref(n), C.byref(st)))
+        return n.value, st.as_dict()
+
+    def join_presplit_u32(self, left_tuples: int, n_left: int, left_lo, left_hi, right_tuples: int, n_right: int,
+                          right_lo, right_hi, n_segments: int, chunks_per_segment: int, out_fk: int, out_y: int,
+                          out_x: int, out_capacity: int):
+        """Join of tuple arrays pre-split into n_segments x chunks_per_segment chunks (segment-major
+        host tables of tuple indices); see include/olap_gpu.h."""
+        n = C.c_uint64()
+        st = JoinStats()
+        self._check(self.lib.olap_join_presplit_u32(self.h, left_tuples, n_left, _u64_table(left_lo), _u64_table(left_hi),
+                                                    right_tuples, n_right, _u64_table(right_lo), _u64_table(right_hi),
+                                                    n_segments, chunks_per_segment, out_fk, out_y, out_x, out_capacity,
+                                                    C.byref(n), C.byref(st)))
         return n.value, st.as_dict()
 
     def join_configure(self, radix_bits_total: int = -1, max_bits_per_pass: int = 0):

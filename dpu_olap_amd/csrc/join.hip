@@ -55,6 +55,9 @@ struct PassSrc {
   const uint64_t* seg_off;  // [n_seg + 1]
   uint32_t n_seg;
   uint32_t blocks_per_seg;
+  // SRC_TUPLES, pre-split input: block k of the grid reads tuples [blk_range[2k], blk_range[2k+1])
+  // (one chunk per sender of an exchanged segment) instead of an even share of its segment
+  const uint64_t* blk_range;
 };
 
 struct TileRange {
@@ -75,6 +78,14 @@ __device__ __forceinline__ TileRange block_tiles(const PassSrc& s) {
     r.lo = r.hi = r.a = 0;
   } else {
     r.seg = blockIdx.x / s.blocks_per_seg;
+    if (s.blk_range) {
+      r.lo = s.blk_range[2 * (uint64_t)blockIdx.x];
+      r.hi = s.blk_range[2 * (uint64_t)blockIdx.x + 1];
+      r.a = r.lo & ~1ull;
+      r.t0 = 0;
+      r.t1 = (r.hi - r.a + TILE - 1) / TILE;
+      return r;
+    }
     const uint32_t j = blockIdx.x - r.seg * s.blocks_per_seg;
     r.lo = s.seg_off[r.seg];
     r.hi = s.seg_off[r.seg + 1];
@@ -953,15 +964,31 @@ static uint64_t seg_blocks(const olap_ctx* ctx, uint64_t n_seg) {
   return b;
 }
 
+// Tuples that arrive already grouped by their leading hash bits (below the skipped ones):
+// segment j fixes `bits` = log2(n_seg) bits and is the union of `chunks` chunks
+// [lo[j*chunks + c], hi[j*chunks + c]) of the tuple array -- one chunk per sender after
+// the fused owner + sub-bucket exchange.  Host arrays.
+struct Presplit {
+  uint32_t n_seg = 0;
+  uint32_t chunks = 0;
+  uint32_t bits = 0;
+  const uint64_t* lo = nullptr;
+  const uint64_t* hi = nullptr;
+};
+
 // workspace bytes one side needs besides its final tuple buffer and the shared temps
-static uint64_t side_scratch_bytes(const olap_ctx* ctx, uint64_t rows, const PassPlan& plan) {
+static uint64_t side_scratch_bytes(const olap_ctx* ctx, uint64_t rows, const PassPlan& plan,
+                                   const Presplit* pre = nullptr) {
   uint64_t bytes = 0;
-  uint64_t n_seg = 1;
+  uint64_t n_seg = pre ? pre->n_seg : 1;
   const uint64_t tiles = (rows + kPTile - 1) / kPTile + 1;
+  if (pre) bytes += align_up((uint64_t)pre->n_seg * pre->chunks * 16, 256) + align_up((n_seg + 1) * 8, 256);
   for (int i = 0; i < plan.passes; ++i) {
     const uint64_t F = 1ull << plan.bits[i];
     uint64_t blocks;
-    if (i == 0) {
+    if (i == 0 && pre) {
+      blocks = n_seg * pre->chunks;
+    } else if (i == 0) {
       blocks = (uint64_t)ctx->compute_units * 2;
       if (blocks > tiles) blocks = tiles;
     } else {
@@ -990,9 +1017,9 @@ static uint32_t region_cap(uint64_t rows, uint64_t P) {
 
 // The last pass may skip its histogram (capacity layout) when every workgroup owns whole
 // input segments and there are enough of them to fill the chip.
-static bool capacity_eligible(const olap_ctx* ctx, uint64_t rows, const PassPlan& plan) {
+static bool capacity_eligible(const olap_ctx* ctx, uint64_t rows, const PassPlan& plan, uint32_t pre_bits = 0) {
   if (!ctx->capacity_mode || ctx->scatter_variant != 0 || plan.passes < 2) return false;
-  const uint64_t P = 1ull << plan.total_bits;
+  const uint64_t P = 1ull << (plan.total_bits + pre_bits);
   const uint64_t n_seg_last = P >> plan.bits[plan.passes - 1];
   return n_seg_last >= (uint64_t)ctx->compute_units && rows / P >= 512;
 }
@@ -1014,13 +1041,40 @@ static uint32_t pass0_tile(const olap_ctx* ctx, const PassPlan& plan) {
 // (key, payload) tuples already in HBM -- what a rank receives from the all-to-all.
 static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, const uint2* tuple_in,
                           uint64_t tuple_n, const PassPlan& plan, uint32_t skip_bits, uint2* tmp0, uint2* tmp1,
-                          uint2* final_tuples, bool capm, unsigned long long* d_overflow, SideOut* so) {
+                          uint2* final_tuples, bool capm, unsigned long long* d_overflow, SideOut* so,
+                          const Presplit* pre = nullptr) {
   const uint64_t rows = tuple_in ? tuple_n : cs.view.total_rows;
   PassSrc src{};
   uint64_t n_seg = 1;
   const uint64_t* seg_in = nullptr;
   const uint2* in_tuples = nullptr;
-  if (tuple_in) {
+  const uint64_t* pre_ranges = nullptr;
+  if (tuple_in && pre) {
+    // pre-split input: upload the chunk table and the dense base of every segment
+    const uint64_t nchunk = (uint64_t)pre->n_seg * pre->chunks;
+    uint64_t* d_rng = (uint64_t*)ws_alloc(ctx, nchunk * 16);
+    uint64_t* d_base = (uint64_t*)ws_alloc(ctx, ((uint64_t)pre->n_seg + 1) * 8);
+    uint64_t* h_rng = (uint64_t*)pinned_alloc(ctx, nchunk * 16);
+    uint64_t* h_base = (uint64_t*)pinned_alloc(ctx, ((uint64_t)pre->n_seg + 1) * 8);
+    if (!d_rng || !d_base || !h_rng || !h_base) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (chunk table)");
+    uint64_t run = 0;
+    for (uint32_t j = 0; j < pre->n_seg; ++j) {
+      h_base[j] = run;
+      for (uint32_t c = 0; c < pre->chunks; ++c) {
+        const uint64_t k = (uint64_t)j * pre->chunks + c;
+        h_rng[2 * k] = pre->lo[k];
+        h_rng[2 * k + 1] = pre->hi[k];
+        run += pre->hi[k] - pre->lo[k];
+      }
+    }
+    h_base[pre->n_seg] = run;
+    OLAP_HIP(ctx, hipMemcpyAsync(d_rng, h_rng, nchunk * 16, hipMemcpyHostToDevice, ctx->stream));
+    OLAP_HIP(ctx, hipMemcpyAsync(d_base, h_base, ((uint64_t)pre->n_seg + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    pre_ranges = d_rng;
+    seg_in = d_base;
+    n_seg = pre->n_seg;
+    in_tuples = tuple_in;
+  } else if (tuple_in) {
     uint64_t* seg0 = (uint64_t*)ws_alloc(ctx, 16);
     uint64_t* h_seg0 = (uint64_t*)pinned_alloc(ctx, 16);
     if (!seg0 || !h_seg0) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (segment table)");
@@ -1034,7 +1088,7 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
     src.key_ptrs = cs.dev_ptr_tables[0];
     src.pay_ptrs = has_payload ? cs.dev_ptr_tables[1] : nullptr;
   }
-  uint32_t consumed = skip_bits;
+  uint32_t consumed = skip_bits + (pre ? pre->bits : 0u);
   OLAP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_scatter<SRC_COLS>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, kScatterLds));
   OLAP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_scatter<SRC_TUPLES>),
@@ -1077,15 +1131,17 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
       if (blocks == 0) blocks = 1;
       bseg = blocks;
     } else {
-      bseg = (capm && i == plan.passes - 1) ? 1 : seg_blocks(ctx, n_seg);
+      const bool ranged = pre_ranges && i == 0;  // one workgroup per chunk of the pre-split input
+      bseg = ranged ? pre->chunks : (capm && i == plan.passes - 1) ? 1 : seg_blocks(ctx, n_seg);
       blocks = n_seg * bseg;
       src.tuples = in_tuples;
       src.seg_off = seg_in;
       src.n_seg = (uint32_t)n_seg;
       src.blocks_per_seg = (uint32_t)bseg;
+      src.blk_range = ranged ? pre_ranges : nullptr;
     }
     if (blocks > 0x7FFFFFFFull) return ctx->fail(OLAP_ERR_INVALID, "partition grid too large");
-    if (capm && i == plan.passes - 1) {  // capacity layout: scatter only
+    if (capm && i == plan.passes - 1 && !src.blk_range) {  // capacity layout: scatter only
       so->cap = region_cap(rows, n_seg * F);
       so->cnt = (uint32_t*)ws_alloc(ctx, n_seg * F * 4);
       so->dense = (uint64_t*)ws_alloc(ctx, n_seg * F * 8);
@@ -1189,6 +1245,8 @@ struct JoinIn {
   int in_mem = OLAP_MEM_DEVICE;
   const uint2* l_tuples = nullptr;
   const uint2* r_tuples = nullptr;
+  const Presplit* l_pre = nullptr;  // both or neither; same n_seg
+  const Presplit* r_pre = nullptr;
 };
 
 static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t* out_y, uint32_t* out_x, int out_mem,
@@ -1203,28 +1261,33 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
   const uint64_t lnb = in.l_tuples ? 0 : in.lnb, rnb = in.r_tuples ? 0 : in.rnb;
   const int in_mem = in.in_mem;
   PassPlan plan;
-  OLAP_TRY(make_plan(ctx, total_bits, &plan));
-  if (plan.total_bits + (uint32_t)ctx->hash_skip_bits > 32)
-    return ctx->fail(OLAP_ERR_INVALID, "radix bits (%u) + skipped hash bits (%d) exceed 32", plan.total_bits, ctx->hash_skip_bits);
-  const uint32_t P = 1u << plan.total_bits;
+  const uint32_t pre_bits = in.l_pre ? in.l_pre->bits : 0u;  // already fixed by the pre-split
+  if (total_bits <= pre_bits) total_bits = pre_bits + 1;
+  OLAP_TRY(make_plan(ctx, total_bits - pre_bits, &plan));
+  if (pre_bits + plan.total_bits + (uint32_t)ctx->hash_skip_bits > 32)
+    return ctx->fail(OLAP_ERR_INVALID, "radix bits (%u) + skipped hash bits (%d) exceed 32", pre_bits + plan.total_bits,
+                     ctx->hash_skip_bits);
+  const uint32_t P = 1u << (pre_bits + plan.total_bits);
   // direct-address LDS table when few enough hash bits remain below the partition bits
-  const uint32_t table_bits = 32u - (uint32_t)ctx->hash_skip_bits - plan.total_bits;
+  const uint32_t table_bits = 32u - (uint32_t)ctx->hash_skip_bits - pre_bits - plan.total_bits;
   const bool direct = ctx->direct_table != 0 && table_bits <= (uint32_t)kDirectBits;
   const uint32_t eb[2] = {4, 4};
   const void* const* lcols[2] = {(const void* const*)lfk, (const void* const*)ly};
   const void* const* rcols[2] = {(const void* const*)rpk, (const void* const*)rx};
   const uint64_t maxN = NL > NR ? NL : NR;
-  const bool lcap = allow_capacity && capacity_eligible(ctx, NL, plan);
-  const bool rcap = allow_capacity && capacity_eligible(ctx, NR, plan);
+  const bool lcap = allow_capacity && capacity_eligible(ctx, NL, plan, pre_bits);
+  const bool rcap = allow_capacity && capacity_eligible(ctx, NR, plan, pre_bits);
   const uint64_t lt_tuples = lcap ? (uint64_t)P * region_cap(NL, P) : NL;
   const uint64_t rt_tuples = rcap ? (uint64_t)P * region_cap(NR, P) : NR;
   uint64_t need = column_set_bytes(lrows, lnb, 2, eb, in_mem) + column_set_bytes(rrows, rnb, 2, eb, in_mem) +
-                  side_scratch_bytes(ctx, NL, plan) + side_scratch_bytes(ctx, NR, plan) +
+                  side_scratch_bytes(ctx, NL, plan, in.l_pre) + side_scratch_bytes(ctx, NR, plan, in.r_pre) +
                   align_up((lt_tuples + 2) * 8, 256) + align_up((rt_tuples + 2) * 8, 256) + 8192;
   if (plan.passes >= 2) need += align_up((maxN + 2) * 8, 256);
   if (plan.passes >= 3) need += align_up((maxN + 2) * 8, 256);
   if (out_mem == OLAP_MEM_HOST) need += 3 * align_up(NL * 4 + 4, 256);
-  OLAP_TRY(pinned_begin(ctx, (lnb + rnb + 2) * 8 * 8 + 8192));
+  uint64_t pin = (lnb + rnb + 2) * 8 * 8 + 8192;
+  if (in.l_pre) pin += 2 * ((uint64_t)in.l_pre->n_seg * in.l_pre->chunks * 16 + ((uint64_t)in.l_pre->n_seg + 1) * 8 + 512);
+  OLAP_TRY(pinned_begin(ctx, pin));
   OLAP_TRY(ws_begin(ctx, need));
   ColumnSet lcs, rcs;
   if (!in.l_tuples) OLAP_TRY(build_column_set(ctx, lcols, 2, eb, lrows, lnb, in_mem, pass0_tile(ctx, plan), &lcs));
@@ -1245,9 +1308,9 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
   OLAP_HIP(ctx, hipMemsetAsync(d_cnt, 0, 40, ctx->stream));
   SideOut lso, rso;
   OLAP_TRY(partition_side(ctx, lcs, true, in.l_tuples, NL, plan, (uint32_t)ctx->hash_skip_bits, tmp0, tmp1, Lt, lcap,
-                          d_cnt + 4, &lso));
+                          d_cnt + 4, &lso, in.l_pre));
   OLAP_TRY(partition_side(ctx, rcs, true, in.r_tuples, NR, plan, (uint32_t)ctx->hash_skip_bits, tmp0, tmp1, Rt, rcap,
-                          d_cnt + 4, &rso));
+                          d_cnt + 4, &rso, in.r_pre));
   {
     PhaseScope ps(ctx, PH_JOIN_PROBE);
     uint64_t grid = (uint64_t)ctx->compute_units * 8;
@@ -1277,7 +1340,7 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
   }
   if (st) {
     st->passes = plan.passes;
-    for (int i = 0; i < 4; ++i) st->radix_bits[i] = plan.bits[i];
+    for (int i = 0; i < 4; ++i) st->radix_bits[i] = i < plan.passes ? plan.bits[i] : 0;
     st->nr_partitions = P;
     st->table_slots = direct ? (1u << table_bits) : (uint32_t)kSlots;
     st->left_rows = NL;
@@ -1312,6 +1375,7 @@ static int join_run(olap_ctx* ctx, const JoinIn& jin, uint64_t NL, uint64_t NR, 
     const int dbits = 32 - kDirectBits - ctx->hash_skip_bits;
     if (ctx->direct_table && dbits >= 1 && dbits < (int)bits && (NR >> dbits) >= 2048) bits = (uint32_t)dbits;
   }
+  if (jin.l_pre && bits <= jin.l_pre->bits) bits = jin.l_pre->bits + 1;  // at least one pass gathers the chunks
   unsigned long long counters[5] = {0, 0, 0, 0, 0};
   bool allow_capacity = true;
   for (int attempt = 0; attempt < 4; ++attempt) {
@@ -1432,6 +1496,53 @@ int olap_join_tuples_u32(olap_ctx* ctx, const uint64_t* left_tuples, uint64_t n_
   jin.l_tuples = reinterpret_cast<const uint2*>(left_tuples);
   jin.r_tuples = reinterpret_cast<const uint2*>(right_tuples);
   return join_run(ctx, jin, n_left, n_right, out_fk, out_y, out_x, out_capacity, OLAP_MEM_DEVICE, out_rows, stats);
+}
+
+static int check_presplit(olap_ctx* ctx, const uint64_t* lo, const uint64_t* hi, uint64_t n_chunks, uint64_t n_tuples,
+                          uint64_t* rows) {
+  uint64_t t = 0;
+  for (uint64_t k = 0; k < n_chunks; ++k) {
+    if (lo[k] > hi[k] || hi[k] > n_tuples) return ctx->fail(OLAP_ERR_INVALID, "chunk %llu lies outside the tuple array", (unsigned long long)k);
+    t += hi[k] - lo[k];
+  }
+  if (t > (1ull << 32)) return ctx->fail(OLAP_ERR_INVALID, "more than 2^32 rows on one side");
+  *rows = t;
+  return OLAP_OK;
+}
+
+int olap_join_presplit_u32(olap_ctx* ctx, const uint64_t* left_tuples, uint64_t n_left, const uint64_t* left_chunk_lo,
+                           const uint64_t* left_chunk_hi, const uint64_t* right_tuples, uint64_t n_right,
+                           const uint64_t* right_chunk_lo, const uint64_t* right_chunk_hi, uint32_t n_segments,
+                           uint32_t chunks_per_segment, uint32_t* out_fk, uint32_t* out_y, uint32_t* out_x,
+                           uint64_t out_capacity, uint64_t* out_rows, olap_join_stats* stats) {
+  if (!ctx) return OLAP_ERR_INVALID;
+  if (hipSetDevice(ctx->device) != hipSuccess) return ctx->fail(OLAP_ERR_DEVICE, "hipSetDevice failed");
+  if (!out_rows) return ctx->fail(OLAP_ERR_INVALID, "out_rows is null");
+  if (n_segments < 1 || (n_segments & (n_segments - 1)) || n_segments > (1u << 16))
+    return ctx->fail(OLAP_ERR_INVALID, "n_segments must be a power of two in [1, 2^16]");
+  if (chunks_per_segment < 1 || chunks_per_segment > 4096) return ctx->fail(OLAP_ERR_INVALID, "chunks_per_segment must be in [1, 4096]");
+  if (!left_chunk_lo || !left_chunk_hi || !right_chunk_lo || !right_chunk_hi) return ctx->fail(OLAP_ERR_INVALID, "null chunk table");
+  if ((n_left && !left_tuples) || (n_right && !right_tuples)) return ctx->fail(OLAP_ERR_INVALID, "null tuple array");
+  if ((((uintptr_t)left_tuples) | ((uintptr_t)right_tuples)) & 15)
+    return ctx->fail(OLAP_ERR_INVALID, "tuple arrays must be 16-byte aligned");
+  const uint64_t nchunk = (uint64_t)n_segments * chunks_per_segment;
+  uint64_t NL = 0, NR = 0;
+  OLAP_TRY(check_presplit(ctx, left_chunk_lo, left_chunk_hi, nchunk, n_left, &NL));
+  OLAP_TRY(check_presplit(ctx, right_chunk_lo, right_chunk_hi, nchunk, n_right, &NR));
+  Presplit lp, rp;
+  lp.n_seg = rp.n_seg = n_segments;
+  lp.chunks = rp.chunks = chunks_per_segment;
+  lp.bits = rp.bits = (uint32_t)ceil_log2_u64(n_segments);
+  lp.lo = left_chunk_lo;
+  lp.hi = left_chunk_hi;
+  rp.lo = right_chunk_lo;
+  rp.hi = right_chunk_hi;
+  JoinIn jin;
+  jin.l_tuples = reinterpret_cast<const uint2*>(left_tuples);
+  jin.r_tuples = reinterpret_cast<const uint2*>(right_tuples);
+  jin.l_pre = &lp;
+  jin.r_pre = &rp;
+  return join_run(ctx, jin, NL, NR, out_fk, out_y, out_x, out_capacity, OLAP_MEM_DEVICE, out_rows, stats);
 }
 
 // Shared body of olap_partition_u32 (keys/payload columns out) and

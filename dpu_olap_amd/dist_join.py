@@ -80,6 +80,22 @@ class GpuLocalOps:
             self.ctx.join_set_hash_skip_bits(0)
         return out[0][:got], out[1][:got], out[2][:got], stats
 
+    def join_presplit(self, lt: torch.Tensor, l_lo, l_hi, rt: torch.Tensor, r_lo, r_hi, n_segments: int, chunks: int,
+                      skip_bits: int = 0):
+        """Local join of exchanged tuples that are still grouped (sender, sub-bucket): the first
+        radix pass reads the chunks in place (olap_join_presplit_u32)."""
+        n = int(lt.numel())
+        out = [self.empty(n) for _ in range(3)]
+        torch.cuda.current_stream(self.device).synchronize()  # inputs come from torch's stream; do not wait for RCCL's
+        self.ctx.join_set_hash_skip_bits(skip_bits)
+        try:
+            got, stats = self.ctx.join_presplit_u32(lt.data_ptr(), n, l_lo, l_hi, rt.data_ptr(), int(rt.numel()), r_lo, r_hi,
+                                                    n_segments, chunks, out[0].data_ptr(), out[1].data_ptr(),
+                                                    out[2].data_ptr(), n)
+        finally:
+            self.ctx.join_set_hash_skip_bits(0)
+        return out[0][:got], out[1][:got], out[2][:got], stats
+
     def join(self, lfk, ly, rpk, rx, skip_bits: int = 0):
         lrows = [int(t.numel()) for t in lfk]
         rrows = [int(t.numel()) for t in rpk]
@@ -155,6 +171,36 @@ def _exchange_counts(cnt_in: torch.Tensor, world: int, group) -> torch.Tensor:
         return torch.stack([gt.view(world, per)[rank] for gt in gathered]).view(-1)
 
 
+FUSED_SPLIT_BITS = 9  # owner bits + sub-bucket bits of the fused split: one 512-bucket pass
+
+
+def _chunk_tables(cnt: torch.Tensor):
+    """cnt[q][j] = tuples sender q holds for sub-bucket j of this rank, in the order they sit in
+    the received buffer (sender-major).  Returns segment-major (lo, hi) tables: chunk (j, q)."""
+    world, S = cnt.shape
+    flat = cnt.reshape(-1)
+    end = torch.cumsum(flat, 0)
+    lo = (end - flat).view(world, S).t().contiguous().view(-1)
+    hi = end.view(world, S).t().contiguous().view(-1)
+    return [int(v) for v in lo], [int(v) for v in hi]
+
+
+def _fused_side(ops, keys, payload, world: int, S: int, group, async_op: bool):
+    """Split one table into world x S buckets (owner = top bits, sub-bucket = next bits), ship
+    every owner its S runs as one message, and return (pending tuples, chunk lo, chunk hi,
+    rows sent, rows received)."""
+    t, off = ops.partition_tuples(keys, payload, world * S)
+    cnt_in = torch.tensor([off[k + 1] - off[k] for k in range(world * S)], dtype=torch.int64, device=t.device)
+    cnt_out = _exchange_counts(cnt_in, world, group).view(world, S).cpu()
+    in_splits = [int(v) for v in cnt_in.view(world, S).sum(1).cpu()]
+    out_splits = [int(v) for v in cnt_out.sum(1)]
+    pend = _exchange(t, in_splits, out_splits, ops.empty_tuples, group, async_op=True)
+    if not async_op:
+        pend = _Pending(pend.wait())
+    lo, hi = _chunk_tables(cnt_out)
+    return pend, lo, hi, in_splits, out_splits
+
+
 def distributed_join(ops, left_batches: Sequence, right_batches: Sequence, group=None, timers: dict | None = None):
     """left_batches / right_batches: this rank's batches as (key, payload) tensor pairs.
     Returns (fk, y, x, info): this rank's shard of the join result (rows whose key it owns)."""
@@ -168,6 +214,21 @@ def distributed_join(ops, left_batches: Sequence, right_batches: Sequence, group
         raise ValueError("the owner split uses the top log2(G) hash bits: world size must be a power of two")
     g = world.bit_length() - 1
     rank = dist.get_rank(group)
+    if hasattr(ops, "join_presplit") and world <= (1 << (FUSED_SPLIT_BITS - 1)) and getattr(ops, "fused", True):
+        # fused path: the owner split IS the first radix pass (world x S = 512 buckets); each
+        # owner receives, per sender, its S sub-bucket runs, and its next pass reads them in
+        # place.  The left table's exchange overlaps the split of the right table.
+        S = (1 << FUSED_SPLIT_BITS) // world
+        pend_l, l_lo, l_hi, l_in, l_out = _fused_side(ops, lfk, ly, world, S, group, async_op=True)
+        pend_r, r_lo, r_hi, r_in, r_out = _fused_side(ops, rpk, rx, world, S, group, async_op=False)
+        RR = pend_r.wait()
+        RL = pend_l.wait()
+        if RL.is_cuda:
+            torch.cuda.current_stream(RL.device).synchronize()
+        fk, y, x, stats = ops.join_presplit(RL, l_lo, l_hi, RR, r_lo, r_hi, S, world, g)
+        sent = sum(l_in) + sum(r_in) - l_in[rank] - r_in[rank]
+        return fk, y, x, {"world": world, "stats": stats, "sent_rows": sent, "recv_left": sum(l_out),
+                          "recv_right": sum(r_out), "path": "fused"}
     if hasattr(ops, "partition_tuples"):
         # zipped path: one int64 tensor per table; the left table's exchange overlaps the
         # owner split of the right table (RCCL runs on its own stream)

@@ -200,6 +200,24 @@ int olap_join_tuples_u32(olap_ctx* ctx, const uint64_t* left_tuples, uint64_t n_
                          uint32_t* out_y, uint32_t* out_x, uint64_t out_capacity, uint64_t* out_rows,
                          olap_join_stats* stats /* may be NULL */);
 
+/* The join on zipped tuples that arrive PRE-SPLIT by their leading hash bits -- what a rank
+ * holds when every sender ran olap_partition_tuples_u32 with nr_partitions = ranks x
+ * n_segments and shipped each owner its n_segments runs in one message.  Segment j fixes
+ * the log2(n_segments) hash bits directly below the skipped ones
+ * (olap_join_set_hash_skip_bits) and is the union of chunks_per_segment chunks
+ * [chunk_lo[j * chunks_per_segment + c], chunk_hi[...]) -- tuple indices into the device
+ * array, host tables, one chunk per sender.  The first radix pass reads the chunks in
+ * place (one workgroup per chunk), so the exchanged data is not re-grouped first.  This
+ * replaces the host-side regrouping of Partitioner::GetOffsets / LoadPartitions
+ * (host/partition/partitioner.cc:280-375) for the multi-device case. */
+int olap_join_presplit_u32(olap_ctx* ctx, const uint64_t* left_tuples, uint64_t n_left,
+                           const uint64_t* left_chunk_lo, const uint64_t* left_chunk_hi,
+                           const uint64_t* right_tuples, uint64_t n_right,
+                           const uint64_t* right_chunk_lo, const uint64_t* right_chunk_hi,
+                           uint32_t n_segments, uint32_t chunks_per_segment, uint32_t* out_fk,
+                           uint32_t* out_y, uint32_t* out_x, uint64_t out_capacity, uint64_t* out_rows,
+                           olap_join_stats* stats /* may be NULL */);
+
 /* Tuning knobs (0 = default).  radix_bits_total < 0 keeps the automatic choice
  * ceil(log2(right_rows / 4096)). */
 int olap_join_configure(olap_ctx* ctx, int radix_bits_total, int max_bits_per_pass);

@@ -60,6 +60,37 @@ class OracleTupleOps(OracleLocalOps):
         return self.join([lk], [lp], [rk], [rp], skip_bits)
 
 
+class OracleFusedOps(OracleTupleOps):
+    """Adds the pre-split join, so distributed_join takes its fused path (owner split = first
+    radix pass).  Checks the chunk tables it is handed: chunk (j, q) must hold only keys
+    whose hash has owner bits = this rank and sub-bucket bits = j."""
+
+    def join_presplit(self, lt, l_lo, l_hi, rt, r_lo, r_hi, n_segments, chunks, skip_bits=0):
+        rank = dist.get_rank()
+        sbits = n_segments.bit_length() - 1
+
+        def gather(t, lo, hi):
+            z = t.contiguous().numpy().view(np.uint64)
+            assert len(lo) == len(hi) == n_segments * chunks
+            assert sum(h - l for l, h in zip(lo, hi)) == z.size, "chunks must tile the received buffer"
+            parts = []
+            for j in range(n_segments):
+                for c in range(chunks):
+                    ch = z[lo[j * chunks + c]:hi[j * chunks + c]]
+                    h = oracle.wang_hash_np((ch & np.uint64(0xFFFFFFFF)).astype(np.uint32))
+                    if skip_bits:
+                        assert ((h >> np.uint32(32 - skip_bits)) == rank).all()
+                    if sbits:
+                        sub = (h << np.uint32(skip_bits)) >> np.uint32(32 - sbits) if skip_bits else h >> np.uint32(32 - sbits)
+                        assert (sub == j).all(), "chunk holds keys of another sub-bucket"
+                    parts.append(ch)
+            return torch.from_numpy(np.concatenate(parts).view(np.int64).copy()) if parts else t
+
+        fk, y, x, st = self.join_tuples(gather(lt, l_lo, l_hi), gather(rt, r_lo, r_hi), skip_bits)
+        st["presplit"] = (n_segments, chunks)
+        return fk, y, x, st
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -80,7 +111,10 @@ def _worker(rank, world, port, case, outdir, tuple_path):
         t = lambda a: torch.from_numpy(a.view(np.int32).copy())
         left = [(t(k), t(p)) for k, p in zip(cut(sl(fk)), cut(sl(y)))]
         right = [(t(k), t(p)) for k, p in zip(cut(sl(pk)), cut(sl(x)))]
-        ofk, oy, ox, info = distributed_join(OracleTupleOps() if tuple_path else OracleLocalOps(), left, right)
+        ops = {"fused": OracleFusedOps, "tuple": OracleTupleOps, "cols": OracleLocalOps}[tuple_path]()
+        ofk, oy, ox, info = distributed_join(ops, left, right)
+        if tuple_path == "fused":
+            assert info["path"] == "fused" and info["stats"]["presplit"] == (512 // world, world)
         u = lambda tt: tt.contiguous().numpy().view(np.uint32)
         np.savez(os.path.join(outdir, f"rank{rank}.npz"), fk=u(ofk), y=u(oy), x=u(ox),
                  sent=np.array([info["sent_rows"]]), skip=np.array([info["stats"]["skip_bits"]]))
@@ -89,7 +123,7 @@ def _worker(rank, world, port, case, outdir, tuple_path):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,tuple_path", [(2, True), (2, False), (4, True)])
+@pytest.mark.parametrize("world,tuple_path", [(2, "fused"), (4, "fused"), (2, "tuple"), (2, "cols"), (4, "tuple")])
 @pytest.mark.parametrize("case", ["a", "b"])
 def test_distributed_join_gloo(tmp_path, world, case, tuple_path):
     port = _free_port()

@@ -583,6 +583,99 @@ def test_multirank_join_loopback_on_one_gpu(dev, world):
     assert tot_rows == n and (tot_sum, tot_xor) == expect
 
 
+@pytest.mark.parametrize("world", [2, 8])
+def test_multirank_fused_split_loopback_on_one_gpu(dev, world):
+    """The fused multi-GPU path: every logical rank splits into G x S = 512 buckets
+    (olap_partition_tuples_u32), rank r receives per sender its S runs (emulated by
+    slicing), and olap_join_presplit_u32 reads those chunks in place.  Union of the shards
+    digests like the whole join."""
+    import torch
+    from dpu_olap_amd import datagen as dg
+    from dpu_olap_amd.dist_join import GpuLocalOps, _chunk_tables
+    device = torch.device("cuda", 0)
+    ops = GpuLocalOps(dev, device)
+    rows, nb = 1 << 18, 16
+    n = rows * nb
+    col = lambda: torch.empty(n, dtype=torch.int32, device=device)
+    fk, y, pk, x, exp = col(), col(), col(), col(), col()
+    dev.gen_fk_u32(fk.data_ptr(), n, dg.SEED, dg.STREAM_FK, 0, rows, rows)
+    dev.gen_uniform_u32(y.data_ptr(), n, dg.SEED, dg.STREAM_Y, 0)
+    dev.gen_index_u32(pk.data_ptr(), n, 0)
+    dev.gen_uniform_u32(x.data_ptr(), n, dg.SEED, dg.STREAM_X, 0)
+    dev.gen_uniform_u32_at(exp.data_ptr(), fk.data_ptr(), n, dg.SEED, dg.STREAM_X)
+    expect = dev.checksum_rows3_u32(fk.data_ptr(), y.data_ptr(), exp.data_ptr(), n)
+    per, S, bits = nb // world, 512 // world, world.bit_length() - 1
+    sends = []
+    for r in range(world):
+        sl = lambda t: [t[(r * per + b) * rows:(r * per + b + 1) * rows] for b in range(per)]
+        sends.append(ops.partition_tuples(sl(fk), sl(y), world * S) + ops.partition_tuples(sl(pk), sl(x), world * S))
+    tsum, txor, trows = 0, 0, 0
+    for r in range(world):
+        def recv(ti, oi):
+            buf = torch.cat([z[ti][z[oi][r * S]:z[oi][(r + 1) * S]] for z in sends])
+            cnt = torch.tensor([[z[oi][r * S + j + 1] - z[oi][r * S + j] for j in range(S)] for z in sends], dtype=torch.int64)
+            return (buf,) + _chunk_tables(cnt)
+        RL, l_lo, l_hi = recv(0, 1)
+        RR, r_lo, r_hi = recv(2, 3)
+        ofk, oy, ox, stats = ops.join_presplit(RL, l_lo, l_hi, RR, r_lo, r_hi, S, world, bits)
+        assert stats["missing_keys"] == 0 and stats["duplicate_keys"] == 0
+        owner = oracle.wang_hash_np(ofk[:4096].cpu().numpy().view(np.uint32)) >> np.uint32(32 - bits)
+        assert (owner == r).all()
+        s_, xo = dev.checksum_rows3_u32(ofk.data_ptr(), oy.data_ptr(), ox.data_ptr(), ofk.numel())
+        tsum = (tsum + s_) & ((1 << 64) - 1)
+        txor ^= xo
+        trows += ofk.numel()
+    assert trows == n and (tsum, txor) == expect
+
+
+@pytest.mark.parametrize("case", ["a", "b"])
+@pytest.mark.parametrize("n_seg,chunks,bits", [(4, 3, -1), (16, 2, 9), (1, 5, 3), (64, 1, 8)])
+def test_join_presplit_matches_golden(dev, golden, case, n_seg, chunks, bits):
+    """olap_join_presplit_u32 on ragged chunks (odd boundaries, an empty sender) against the
+    Arrow golden join; rows compared as sorted sets."""
+    import torch
+    from dpu_olap_amd.dist_join import GpuLocalOps, _chunk_tables
+    device = torch.device("cuda", 0)
+    ops = GpuLocalOps(dev, device)
+    t = lambda a: torch.from_numpy(a.view(np.int32).copy()).to(device)
+    fk, y, pk, x = (golden[f"join_{case}_{k}"] for k in ("fk", "y", "pk", "x"))
+
+    def side(k, p):
+        cuts = np.linspace(0, k.size, chunks + 1).astype(np.int64)
+        cuts = np.minimum(cuts | 1, k.size) if chunks > 1 else cuts      # odd boundaries
+        cuts[0], cuts[-1] = 0, k.size
+        if chunks > 2:
+            cuts[2] = cuts[1]                                            # sender 1 sends nothing
+        parts, cnt = [], []
+        for c in range(chunks):
+            kk, pp = k[cuts[c]:cuts[c + 1]], p[cuts[c]:cuts[c + 1]]
+            if n_seg > 1 and kk.size:
+                z, off = ops.partition_tuples([t(kk)], [t(pp)], n_seg)
+            else:
+                z = (torch.from_numpy((kk.astype(np.uint64) | (pp.astype(np.uint64) << np.uint64(32))).view(np.int64).copy()).to(device))
+                off = [0, kk.size] if n_seg == 1 else [0] * (n_seg + 1)
+            parts.append(z)
+            cnt.append([off[j + 1] - off[j] for j in range(n_seg)])
+        buf = torch.cat(parts) if parts else ops.empty_tuples(0)
+        pad = ops.empty_tuples(buf.numel() + 2)                          # 16-B aligned base, slack for the tail vector
+        pad[:buf.numel()] = buf
+        return (pad[:buf.numel()],) + _chunk_tables(torch.tensor(cnt, dtype=torch.int64))
+
+    L, l_lo, l_hi = side(fk, y)
+    R, r_lo, r_hi = side(pk, x)
+    dev.join_configure(bits, 0)
+    try:
+        ofk, oy, ox, stats = ops.join_presplit(L, l_lo, l_hi, R, r_lo, r_hi, n_seg, chunks, 0)
+    finally:
+        dev.join_configure(-1, 0)
+    assert stats["nr_partitions"] >= 2 * n_seg and stats["missing_keys"] == 0
+    u = lambda tt: tt.cpu().numpy().view(np.uint32)
+    rfk, ry, rx = sort_rows(u(ofk), u(oy), u(ox))
+    np.testing.assert_array_equal(rfk, golden[f"join_{case}_out_fk"])
+    np.testing.assert_array_equal(ry, golden[f"join_{case}_out_y"])
+    np.testing.assert_array_equal(rx, golden[f"join_{case}_out_x"])
+
+
 @pytest.mark.parametrize("t", ["u32", "i64"])
 def test_take_lds_window_kernel_many_small_batches(dev, t):
     """>= #CU batches of <= 512 KiB with <= 8192 indices each take the LDS-window kernel
