@@ -7,6 +7,7 @@
 //   BM_Take{Native,Gpu}   {SF, 4Mi, 512Ki, ..} and {SF<<6, 64Ki, 8Ki, ..}   (items = DATA rows)
 //   BM_Sum{Native,Gpu}    {SF, 2Mi, ..} and {SF<<5, 64Ki, ..}
 //   BM_JoinNative         {SF<<5, 64Ki, 64Ki, Partitioned 1|0};  BM_JoinGpu {SF, 2Mi, 2Mi, GPUs}
+//   BM_PartitionGpu       {SF, 2Mi, GPUs, Partitions = max(SF, 2)}
 // Prepare() runs inside the timed region like in the reference; filter/take/sum force one
 // iteration; {0,...} argument rows free the generated batches between shapes.
 #include <arrow/compute/api.h>
@@ -289,6 +290,43 @@ BENCHMARK_REGISTER_F(JoinFixture, BM_JoinNative)
 BENCHMARK_REGISTER_F(JoinFixture, BM_JoinGpu)
     ->ArgNames({"Batches", "L-Batch-Size", "R-Batch-Size", "GPUs"})
     ->Args({variables::scale_factor(), 2 << 20, 2 << 20, variables::max_gpus()})
+    ->MeasureProcessCPUTime()->UseRealTime()->Unit(benchmark::kMillisecond);
+
+// --------------------------------------------------------------- partition
+// The standalone radix partition (the reference registers it DISABLED_, its operator is a
+// stub: partition_benchmark.cc:71,117-127, partition_dpu.cc:50-135): batches {pk, v1} random,
+// output = one record batch per partition.
+class PartitionFixture : public benchmark::Fixture {
+ public:
+  PartitionFixture() : rng_(42) {}
+  void SetUp(benchmark::State& state) override {
+    const int num_batches = (int)state.range(0), batch_size = (int)state.range(1);
+    if (num_batches == (int)batches_.size() && batch_size == batches_.front()->num_rows()) return;
+    schema_ = arrow::schema({arrow::field("pk", arrow::uint32(), false), arrow::field("v1", arrow::uint32(), false)});
+    batches_ = generator::MakeRandomRecordBatches(rng_, schema_, num_batches, batch_size);
+  }
+  void TearDown(benchmark::State&) override { batches_.clear(); }
+
+ protected:
+  arrow::random::RandomArrayGenerator rng_;
+  std::shared_ptr<arrow::Schema> schema_;
+  arrow::RecordBatchVector batches_;
+};
+
+BENCHMARK_DEFINE_F(PartitionFixture, BM_PartitionGpu)(benchmark::State& state) {
+  auto dev = DeviceOrSkip(state);
+  if (!dev) return;
+  partition::PartitionGpu op{*dev, schema_, batches_, (uint32_t)state.range(3), "pk"};
+  int64_t rows = 0;
+  TimedLoop(state, op, [&](const arrow::RecordBatchVector& parts) {
+    for (const auto& p : parts) rows += p->num_rows();
+  });
+  std::cout << "Total Rows: " << rows << " Iterations: " << state.iterations() << std::endl;
+  CountRows(state, state.range(0) * state.range(1) * schema_->num_fields());
+}
+BENCHMARK_REGISTER_F(PartitionFixture, BM_PartitionGpu)
+    ->ArgNames({"Batches", "Batch-Size", "GPUs", "Partitions"})
+    ->Args({variables::scale_factor(), 2 << 20, variables::max_gpus(), std::max(2, variables::scale_factor())})
     ->MeasureProcessCPUTime()->UseRealTime()->Unit(benchmark::kMillisecond);
 
 }  // namespace

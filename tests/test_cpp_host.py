@@ -40,7 +40,8 @@ def test_native_operators_and_registry(host_build):
     for frag in ("BM_FilterNative/Batches:256/Batch-Size:65536/Threads:", "BM_FilterGpu/Batches:256/Batch-Size:65536/GPUs:1",
                  "BM_TakeGpu/Batches:2/Batch-Size:4194304/Indices-Batch-Size:524288/GPUs:1",
                  "BM_SumGpu/Batches:64/Batch-Size:65536/GPUs:1", "BM_JoinNative/Batches:64/L-Batch-Size:65536/R-Batch-Size:65536/Partitioned:1",
-                 "BM_JoinGpu/Batches:2/L-Batch-Size:2097152/R-Batch-Size:2097152/GPUs:1"):
+                 "BM_JoinGpu/Batches:2/L-Batch-Size:2097152/R-Batch-Size:2097152/GPUs:1",
+                 "BM_PartitionGpu/Batches:2/Batch-Size:2097152/GPUs:1/Partitions:2"):
         assert frag in names, frag
 
 
@@ -63,6 +64,15 @@ def test_bm_filter_native_plumbing_json(host_build, tmp_path):
     assert parts["Batches"] == "128" and parts["Batch-Size"] == "65536"
     skipped = [x for x in d["benchmarks"] if "Batches:0" in x["name"]][0]
     assert skipped["error_occurred"]
+    # the CSV flattening used by the sweep script (role of the reference's scripts/parse_results.py)
+    import csv
+    r = subprocess.run(["python3", os.path.join(ROOT, "scripts", "results_to_csv.py"), str(tmp_path)], capture_output=True,
+                       text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    rows = list(csv.DictReader(open(tmp_path / "bm.csv")))
+    assert rows and all(row["operator"] == "BM_FilterNative" for row in rows)
+    assert rows[0]["Batches"] == "128" and rows[0]["Batch-Size"] == "65536" and float(rows[0]["real_time"]) > 0
+    assert not any(row["Batches"] == "0" for row in rows)          # skipped rows are dropped
 
 
 @pytest.mark.gpu
@@ -82,7 +92,7 @@ def test_cpp_gpu_benchmarks_run(host_build, tmp_path):
     d = json.load(open(out_json))
     ran = [b for b in d["benchmarks"] if not b.get("error_occurred")]
     names = " ".join(b["name"] for b in ran)
-    for frag in ("BM_FilterGpu", "BM_TakeGpu", "BM_SumGpu", "BM_JoinGpu"):
+    for frag in ("BM_FilterGpu", "BM_TakeGpu", "BM_SumGpu", "BM_JoinGpu", "BM_PartitionGpu"):
         assert frag in names
     f = [b for b in ran if "BM_FilterGpu" in b["name"]][0]
     assert abs(f["Results (AVG)"] / f["Processed (AVG)"] - 0.25) < 0.01
