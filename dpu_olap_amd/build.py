@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libolap_gpu.so")
-SOURCES = ["ctx.hip", "scan_ops.hip", "join.hip", "gen.hip"]
+SOURCES = ["ctx.hip", "stage.hip", "scan_ops.hip", "join.hip", "gen.hip"]
 ARCH = "gfx950"
 
 

@@ -44,6 +44,10 @@ struct PhaseTimer {
 }  // namespace olap
 
 // The opaque handle of include/olap_gpu.h.
+namespace olap {
+class Stager;  // pinned-ring host <-> HBM staging (stage.hip)
+}
+
 struct olap_ctx {
   int device = 0;
   int compute_units = 0;
@@ -82,6 +86,11 @@ struct olap_ctx {
   int capacity_mode = 1;   // last radix pass without histogram (fixed-capacity regions + exact fallback)
   int hash_skip_bits = 0;  // top hash bits already fixed by an upstream owner split
 
+  // OLAP_MEM_HOST operands
+  olap::Stager* stager = nullptr;
+  int host_stage = 1;         // 1: pinned ring + copy threads; 0: plain hipMemcpyAsync per buffer (A/B)
+  int host_copy_threads = 0;  // 0: min(hardware threads, 8)
+
   int fail(int code, const char* fmt, ...) const {
     char buf[512];
     va_list ap;
@@ -117,6 +126,16 @@ void* pinned_alloc(olap_ctx* ctx, uint64_t bytes);
 void phase_begin(olap_ctx* ctx, int phase);                  // record start event if profiling
 void phase_end(olap_ctx* ctx, int phase);                    // record stop event if profiling
 int resolve_timers(olap_ctx* ctx);                           // after a sync: fold pending events
+
+// ---- host <-> HBM staging (stage.hip)
+struct StageItem {
+  void* dev;
+  void* host;
+  uint64_t bytes;
+};
+int stage_h2d(olap_ctx* ctx, const std::vector<StageItem>& items);  // enqueued on ctx->stream when it returns
+int stage_d2h(olap_ctx* ctx, const std::vector<StageItem>& items);  // host buffers filled when it returns
+void stager_destroy(olap_ctx* ctx);
 
 struct PhaseScope {
   olap_ctx* ctx;

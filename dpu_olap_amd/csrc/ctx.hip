@@ -167,17 +167,21 @@ int build_column_set(olap_ctx* ctx, const void* const* const* cols, int ncols,
     const void** d_ptrs = (const void**)ws_alloc(ctx, (nb ? nb : 1) * 8);
     if (!h_ptrs || !d_ptrs) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (ptr tables)");
     if (in_mem == OLAP_MEM_HOST) {
-      PhaseScope ps(ctx, PH_COPY_TO);
+      // staged copies of the batches, back to back in the arena: one DMA per pinned slot
+      std::vector<StageItem> items;
+      items.reserve(nb);
       for (uint64_t b = 0; b < nb; ++b) {
         uint64_t bytes = rows[b] * elem_bytes[c];
         char* d = (char*)ws_alloc(ctx, bytes ? bytes : 1);
         if (!d) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (staging)");
         if (bytes) {
           if (!cols[c][b]) return ctx->fail(OLAP_ERR_INVALID, "null batch pointer (column %d batch %llu)", c, (unsigned long long)b);
-          OLAP_HIP(ctx, hipMemcpyAsync(d, cols[c][b], bytes, hipMemcpyHostToDevice, ctx->stream));
+          items.push_back(StageItem{d, const_cast<void*>(cols[c][b]), bytes});
         }
         h_ptrs[b] = d;
       }
+      PhaseScope ps(ctx, PH_COPY_TO);
+      OLAP_TRY(stage_h2d(ctx, items));
     } else {
       for (uint64_t b = 0; b < nb; ++b) {
         if (rows[b] && !cols[c][b])
@@ -232,6 +236,7 @@ void olap_destroy(olap_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   resolve_timers(ctx);
   for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
+  stager_destroy(ctx);
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);

@@ -1333,9 +1333,7 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
   OLAP_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (out_mem == OLAP_MEM_HOST && counters[2] == 0 && counters[0] == 0 && counters[4] == 0 && NL) {
     PhaseScope ps(ctx, PH_COPY_FROM);
-    OLAP_HIP(ctx, hipMemcpyAsync(out_fk, d_fk, NL * 4, hipMemcpyDeviceToHost, ctx->stream));
-    OLAP_HIP(ctx, hipMemcpyAsync(out_y, d_y, NL * 4, hipMemcpyDeviceToHost, ctx->stream));
-    OLAP_HIP(ctx, hipMemcpyAsync(out_x, d_x, NL * 4, hipMemcpyDeviceToHost, ctx->stream));
+    OLAP_TRY(stage_d2h(ctx, {StageItem{d_fk, out_fk, NL * 4}, StageItem{d_y, out_y, NL * 4}, StageItem{d_x, out_x, NL * 4}}));
     OLAP_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
   if (st) {
@@ -1429,6 +1427,16 @@ int olap_set_tuning(olap_ctx* ctx, const char* key, int value) {
   }
   if (!std::strcmp(key, "take_variant")) {
     ctx->take_variant = value;
+    return OLAP_OK;
+  }
+  if (!std::strcmp(key, "host_stage")) {
+    ctx->host_stage = value != 0;
+    return OLAP_OK;
+  }
+  if (!std::strcmp(key, "host_copy_threads")) {
+    if (value < 0 || value > 256) return ctx->fail(OLAP_ERR_INVALID, "host_copy_threads must be in [0, 256]");
+    if (value != ctx->host_copy_threads) stager_destroy(ctx);  // rebuilt with the new pool on next use
+    ctx->host_copy_threads = value;
     return OLAP_OK;
   }
   if (!std::strcmp(key, "probe_variant")) {
@@ -1601,8 +1609,7 @@ static int partition_run(olap_ctx* ctx, const uint32_t* const* key_ptrs, const u
   OLAP_HIP(ctx, hipMemcpyAsync(out_offsets, pso.off, ((uint64_t)nr_partitions + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
   if (!zipped && out_mem == OLAP_MEM_HOST && N) {
     PhaseScope ps(ctx, PH_COPY_FROM);
-    OLAP_HIP(ctx, hipMemcpyAsync(out_keys, d_k, N * 4, hipMemcpyDeviceToHost, ctx->stream));
-    OLAP_HIP(ctx, hipMemcpyAsync(out_payload, d_p, N * 4, hipMemcpyDeviceToHost, ctx->stream));
+    OLAP_TRY(stage_d2h(ctx, {StageItem{d_k, out_keys, N * 4}, StageItem{d_p, out_payload, N * 4}}));
   }
   OLAP_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return resolve_timers(ctx);

@@ -426,6 +426,16 @@ static int run_sum(olap_ctx* ctx, const void* const* ptrs, const uint64_t* rows,
   return resolve_timers(ctx);
 }
 
+// Packs per-batch results (src[b][0 .. off[b+1]-off[b])) back to back: dense[off[b] + i].
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_pack(const void* const* src, const uint64_t* off, uint32_t nb, T* dense) {
+  for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
+    const T* in = static_cast<const T*>(src[b]);
+    const uint64_t o = off[b], n = off[b + 1] - o;
+    for (uint64_t i = threadIdx.x; i < n; i += kBlock) dense[o + i] = in[i];
+  }
+}
+
 template <typename T>
 static int run_filter(olap_ctx* ctx, const void* const* ptrs, const uint64_t* rows, uint64_t nb, int in_mem,
                       const void* threshold, void* const* out_ptrs, int out_mem, uint64_t* out_rows,
@@ -461,8 +471,9 @@ static int run_filter(olap_ctx* ctx, const void* const* ptrs, const uint64_t* ro
                     align_up(n_seg_est * 12, 256) * 2 + 8192;
     if (out_mem == OLAP_MEM_HOST) {
       for (uint64_t b = b0; b < b1; ++b) need += align_up(rows[b] * eb, 256);
+      need += align_up(total_rows * eb + 16, 256) + align_up((cnt + 1) * 8, 256);  // packed copy + its offsets
     }
-    OLAP_TRY(pinned_begin(ctx, (cnt + 1) * 8 * 6 + 4096));
+    OLAP_TRY(pinned_begin(ctx, (cnt + 1) * 8 * 8 + 4096));
     OLAP_TRY(ws_begin(ctx, need));
     ColumnSet cs;
     OLAP_TRY(build_column_set(ctx, cols, 1, &eb, rows + b0, cnt, in_mem, seg_rows, &cs));
@@ -511,11 +522,27 @@ static int run_filter(olap_ctx* ctx, const void* const* ptrs, const uint64_t* ro
       out_rows[b0 + b] = h_rows[b];
       grand += h_rows[b];
     }
-    if (out_mem == OLAP_MEM_HOST) {
+    if (out_mem == OLAP_MEM_HOST && cnt) {
+      // the per-batch results sit in worst-case-sized staging: pack them back to back so
+      // the way out is a few large DMAs instead of one per batch
+      uint64_t* h_off = (uint64_t*)pinned_alloc(ctx, (cnt + 1) * 8);
+      uint64_t* d_off = (uint64_t*)ws_alloc(ctx, (cnt + 1) * 8);
+      if (!h_off || !d_off) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (pack offsets)");
+      h_off[0] = 0;
+      for (uint64_t b = 0; b < cnt; ++b) h_off[b + 1] = h_off[b] + h_rows[b];
+      T* dense = (T*)ws_alloc(ctx, h_off[cnt] * eb + 16);
+      if (!dense) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (packed filter output)");
+      std::vector<StageItem> items;
+      items.reserve(cnt);
+      for (uint64_t b = 0; b < cnt; ++b)
+        if (h_rows[b]) items.push_back(StageItem{dense + h_off[b], out_ptrs[b0 + b], h_rows[b] * eb});
       PhaseScope ps(ctx, PH_COPY_FROM);
-      for (uint64_t b = 0; b < cnt; ++b) {
-        if (h_rows[b])
-          OLAP_HIP(ctx, hipMemcpyAsync(out_ptrs[b0 + b], h_out[b], h_rows[b] * eb, hipMemcpyDeviceToHost, ctx->stream));
+      if (h_off[cnt]) {
+        OLAP_HIP(ctx, hipMemcpyAsync(d_off, h_off, (cnt + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL((k_pack<T>), dim3((unsigned)std::min<uint64_t>(cnt, 65535u * 16u)), dim3(kBlock), 0, ctx->stream,
+                           (const void* const*)d_out_tbl, (const uint64_t*)d_off, (uint32_t)cnt, dense);
+        OLAP_HIP(ctx, hipGetLastError());
+        OLAP_TRY(stage_d2h(ctx, items));
       }
     }
     OLAP_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -599,11 +626,12 @@ static int run_take(olap_ctx* ctx, const void* const* data_ptrs, const uint64_t*
       OLAP_HIP(ctx, hipGetLastError());
     }
     if (out_mem == OLAP_MEM_HOST) {
+      std::vector<StageItem> items;
+      items.reserve(cnt);
+      for (uint64_t b = 0; b < cnt; ++b)
+        if (idx_rows[b0 + b]) items.push_back(StageItem{h_out[b], out_ptrs[b0 + b], idx_rows[b0 + b] * eb});
       PhaseScope ps(ctx, PH_COPY_FROM);
-      for (uint64_t b = 0; b < cnt; ++b) {
-        if (idx_rows[b0 + b])
-          OLAP_HIP(ctx, hipMemcpyAsync(out_ptrs[b0 + b], h_out[b], idx_rows[b0 + b] * eb, hipMemcpyDeviceToHost, ctx->stream));
-      }
+      OLAP_TRY(stage_d2h(ctx, items));
     }
     OLAP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     b0 = b1;

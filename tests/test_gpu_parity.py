@@ -716,3 +716,53 @@ def test_take_large_batches_small_tile_kernel(dev):
             dev.set_tuning("take_variant", 0)
         for b in range(3):
             np.testing.assert_array_equal(dev.to_host(res[b]), oracle.take(data[b], idx[b]))
+
+
+# ------------------------------------------------------- host staging ring
+@pytest.mark.parametrize("stage,threads", [(1, 0), (1, 1), (1, 3), (0, 0)])
+def test_host_operands_through_the_pinned_ring(dev, stage, threads):
+    """OLAP_MEM_HOST operands larger than one 32 MiB pinned slot, ragged batches (so windows
+    cut batches and span many of them), host results: filter / sum / take / partition / join
+    against the oracle, with the ring (1, 3 or default copy threads) and with the plain
+    per-buffer copies (host_stage=0)."""
+    o = _ops()
+    dev.set_tuning("host_stage", stage)
+    dev.set_tuning("host_copy_threads", threads)
+    try:
+        rng = np.random.default_rng(11)
+        sizes = [int(x) for x in rng.integers(1, 400_000, size=120)] + [9_000_001, 0, 5]
+        batches = [rng.integers(0, 1 << 32, size=n, dtype=np.uint32) for n in sizes]     # ~130 MB
+        res = o.FilterGpu(dev, batches).Prepare().GetResult()
+        for b in (0, 1, 57, 119, 120, 121, 122):
+            np.testing.assert_array_equal(res[b], oracle.filter_lt(batches[b], 1 << 30))
+        assert sum(r.size for r in res) == sum(oracle.filter_lt(b, 1 << 30).size for b in batches)
+        assert o.SumGpu(dev, batches).Prepare().Run() == sum(int(b.sum(dtype=np.uint64)) for b in batches)
+        b64 = [rng.integers(-(1 << 62), 1 << 62, size=n, dtype=np.int64) for n in sizes[:40]]
+        res = o.FilterGpu(dev, b64, threshold=0).Prepare().GetResult()
+        for b in (0, 13, 39):
+            np.testing.assert_array_equal(res[b], b64[b][b64[b] < 0])
+        data = [b for b in batches if b.size]
+        idx = [rng.integers(0, d.size, size=min(d.size, 70_000), dtype=np.uint32) for d in data]
+        out = o.TakeGpu(dev, data, idx).Prepare().Run()
+        for b in (0, 60, len(data) - 1):
+            np.testing.assert_array_equal(out[b], data[b][idx[b]])
+        # join: 12 M x 10 M rows in ragged host batches, host result columns
+        nr = 10_000_000
+        pk = rng.permutation(nr).astype(np.uint32)
+        x = rng.integers(0, 1 << 32, size=nr, dtype=np.uint32)
+        fk = rng.integers(0, nr, size=12_000_000, dtype=np.uint32)
+        y = rng.integers(0, 1 << 32, size=fk.size, dtype=np.uint32)
+        cut = lambda a, k: np.array_split(a, k)
+        j = o.JoinGpu(dev, list(zip(cut(fk, 7), cut(y, 7))), list(zip(cut(pk, 5), cut(x, 5)))).Prepare()
+        r = j.Run()
+        ofk, oy, ox = r["fk"], r["y"], r["x"]
+        lut = np.empty(nr, np.uint32)
+        lut[pk] = x
+        assert ofk.size == fk.size
+        np.testing.assert_array_equal(ox, lut[ofk])
+        a, b_, c = sort_rows(ofk, oy, ox)
+        e = sort_rows(fk, y, lut[fk])
+        np.testing.assert_array_equal(a, e[0]); np.testing.assert_array_equal(b_, e[1]); np.testing.assert_array_equal(c, e[2])
+    finally:
+        dev.set_tuning("host_stage", 1)
+        dev.set_tuning("host_copy_threads", 0)
