@@ -345,8 +345,10 @@ class Context:
                  out_capacity: int, out_mem: int):
         n = C.c_uint64()
         st = JoinStats()
-        self._check(self.lib.olap_join_u32(self.h, _ptr_table(lfk), _ptr_table(ly), _u64_table(lrows), len(lfk),
-                                           _ptr_table(rpk), _ptr_table(rx), _u64_table(rrows), len(rpk), in_mem,
+        lyt = _ptr_table(ly) if ly is not None else None   # None: out_y / out_x are row indices
+        rxt = _ptr_table(rx) if rx is not None else None
+        self._check(self.lib.olap_join_u32(self.h, _ptr_table(lfk), lyt, _u64_table(lrows), len(lfk),
+                                           _ptr_table(rpk), rxt, _u64_table(rrows), len(rpk), in_mem,
                                            out_fk, out_y, out_x, out_capacity, out_mem, C.byref(n), C.byref(st)))
         return n.value, st.as_dict()
 

@@ -977,11 +977,12 @@ struct Presplit {
 };
 
 // workspace bytes one side needs besides its final tuple buffer and the shared temps
-static uint64_t side_scratch_bytes(const olap_ctx* ctx, uint64_t rows, const PassPlan& plan,
+static uint64_t side_scratch_bytes(const olap_ctx* ctx, uint64_t rows, uint64_t n_batches, const PassPlan& plan,
                                    const Presplit* pre = nullptr) {
   uint64_t bytes = 0;
   uint64_t n_seg = pre ? pre->n_seg : 1;
-  const uint64_t tiles = (rows + kPTile - 1) / kPTile + 1;
+  // upper bound of pass-0 tiles: the smaller tile geometry, every batch rounded up on its own
+  const uint64_t tiles = rows / 4096 + n_batches + 1;
   if (pre) bytes += align_up((uint64_t)pre->n_seg * pre->chunks * 16, 256) + align_up((n_seg + 1) * 8, 256);
   for (int i = 0; i < plan.passes; ++i) {
     const uint64_t F = 1ull << plan.bits[i];
@@ -1279,8 +1280,9 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
   const bool rcap = allow_capacity && capacity_eligible(ctx, NR, plan, pre_bits);
   const uint64_t lt_tuples = lcap ? (uint64_t)P * region_cap(NL, P) : NL;
   const uint64_t rt_tuples = rcap ? (uint64_t)P * region_cap(NR, P) : NR;
-  uint64_t need = column_set_bytes(lrows, lnb, 2, eb, in_mem) + column_set_bytes(rrows, rnb, 2, eb, in_mem) +
-                  side_scratch_bytes(ctx, NL, plan, in.l_pre) + side_scratch_bytes(ctx, NR, plan, in.r_pre) +
+  const bool l_pay = ly != nullptr, r_pay = rx != nullptr;  // null payload: the tuple carries its global row index
+  uint64_t need = column_set_bytes(lrows, lnb, l_pay ? 2 : 1, eb, in_mem) + column_set_bytes(rrows, rnb, r_pay ? 2 : 1, eb, in_mem) +
+                  side_scratch_bytes(ctx, NL, lnb, plan, in.l_pre) + side_scratch_bytes(ctx, NR, rnb, plan, in.r_pre) +
                   align_up((lt_tuples + 2) * 8, 256) + align_up((rt_tuples + 2) * 8, 256) + 8192;
   if (plan.passes >= 2) need += align_up((maxN + 2) * 8, 256);
   if (plan.passes >= 3) need += align_up((maxN + 2) * 8, 256);
@@ -1290,8 +1292,8 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
   OLAP_TRY(pinned_begin(ctx, pin));
   OLAP_TRY(ws_begin(ctx, need));
   ColumnSet lcs, rcs;
-  if (!in.l_tuples) OLAP_TRY(build_column_set(ctx, lcols, 2, eb, lrows, lnb, in_mem, pass0_tile(ctx, plan), &lcs));
-  if (!in.r_tuples) OLAP_TRY(build_column_set(ctx, rcols, 2, eb, rrows, rnb, in_mem, pass0_tile(ctx, plan), &rcs));
+  if (!in.l_tuples) OLAP_TRY(build_column_set(ctx, lcols, l_pay ? 2 : 1, eb, lrows, lnb, in_mem, pass0_tile(ctx, plan), &lcs));
+  if (!in.r_tuples) OLAP_TRY(build_column_set(ctx, rcols, r_pay ? 2 : 1, eb, rrows, rnb, in_mem, pass0_tile(ctx, plan), &rcs));
   uint2* tmp0 = plan.passes >= 2 ? (uint2*)ws_alloc(ctx, (maxN + 2) * 8) : nullptr;
   uint2* tmp1 = plan.passes >= 3 ? (uint2*)ws_alloc(ctx, (maxN + 2) * 8) : nullptr;
   uint2* Lt = (uint2*)ws_alloc(ctx, (lt_tuples + 2) * 8);
@@ -1307,9 +1309,9 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
     return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (join buffers)");
   OLAP_HIP(ctx, hipMemsetAsync(d_cnt, 0, 40, ctx->stream));
   SideOut lso, rso;
-  OLAP_TRY(partition_side(ctx, lcs, true, in.l_tuples, NL, plan, (uint32_t)ctx->hash_skip_bits, tmp0, tmp1, Lt, lcap,
+  OLAP_TRY(partition_side(ctx, lcs, l_pay, in.l_tuples, NL, plan, (uint32_t)ctx->hash_skip_bits, tmp0, tmp1, Lt, lcap,
                           d_cnt + 4, &lso, in.l_pre));
-  OLAP_TRY(partition_side(ctx, rcs, true, in.r_tuples, NR, plan, (uint32_t)ctx->hash_skip_bits, tmp0, tmp1, Rt, rcap,
+  OLAP_TRY(partition_side(ctx, rcs, r_pay, in.r_tuples, NR, plan, (uint32_t)ctx->hash_skip_bits, tmp0, tmp1, Rt, rcap,
                           d_cnt + 4, &rso, in.r_pre));
   {
     PhaseScope ps(ctx, PH_JOIN_PROBE);
@@ -1475,8 +1477,6 @@ int olap_join_u32(olap_ctx* ctx, const uint32_t* const* left_fk_ptrs, const uint
   uint64_t NL = 0, NR = 0;
   OLAP_TRY(check_side(ctx, left_fk_ptrs, left_rows, n_left_batches, &NL));
   OLAP_TRY(check_side(ctx, right_pk_ptrs, right_rows, n_right_batches, &NR));
-  if ((n_left_batches && !left_y_ptrs) || (n_right_batches && !right_x_ptrs))
-    return ctx->fail(OLAP_ERR_INVALID, "null payload table");
   JoinIn jin;
   jin.lfk = left_fk_ptrs;
   jin.ly = left_y_ptrs;
@@ -1578,7 +1578,7 @@ static int partition_run(olap_ctx* ctx, const uint32_t* const* key_ptrs, const u
   const uint32_t eb[2] = {4, 4};
   const int ncols = payload_ptrs ? 2 : 1;
   const void* const* cols[2] = {(const void* const*)key_ptrs, (const void* const*)payload_ptrs};
-  uint64_t need = column_set_bytes(rows, n_batches, ncols, eb, in_mem) + side_scratch_bytes(ctx, N, plan) +
+  uint64_t need = column_set_bytes(rows, n_batches, ncols, eb, in_mem) + side_scratch_bytes(ctx, N, n_batches, plan) +
                   align_up((N + 2) * 8, 256) * (uint64_t)(plan.passes >= 3 ? 3 : plan.passes) + 8192;
   if (out_mem == OLAP_MEM_HOST) need += 2 * align_up(N * 4 + 4, 256);
   OLAP_TRY(pinned_begin(ctx, (n_batches + 2) * 8 * 4 + ((uint64_t)nr_partitions + 1) * 8 + 8192));

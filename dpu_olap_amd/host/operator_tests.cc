@@ -196,6 +196,37 @@ TEST(JoinTest, LargeTest) {
     EXPECT_TRUE(native->GetColumnByName(name)->Equals(gpu->GetColumnByName(name)));
 }
 
+TEST(JoinTest, WideTablesGoThroughSelectionVectors) {
+  // several non-key columns per side, mixed widths: the join returns row ids
+  // and every column is gathered through them (the reference's probe + take per column)
+  arrow::random::RandomArrayGenerator rng(5);
+  const int num_batches = 24, batch_size = 50021;
+  auto dev = Gpu();
+  auto rschema = arrow::schema({arrow::field("x1", arrow::uint64(), false), arrow::field("x2", arrow::uint32(), false)});
+  auto lschema = arrow::schema({arrow::field("y1", arrow::uint32(), false), arrow::field("y2", arrow::int64(), false),
+                                arrow::field("y3", arrow::int32(), false)});
+  auto right = AddColumn("pk", MakeRandomRecordBatches(rng, rschema, num_batches, batch_size),
+                         MakeIndexColumn(num_batches, batch_size).ValueOrDie());
+  auto left = AddColumn("fk", MakeRandomRecordBatches(rng, lschema, num_batches, batch_size),
+                        MakeForeignKeyColumn(rng, batch_size, num_batches, batch_size).ValueOrDie());
+  auto native = SortedBy(Go(join::JoinNative{left[0]->schema(), right[0]->schema(), left, right}).ValueOrDie(), {"fk", "y1", "y2"});
+  auto got = Go(join::JoinGpu{*dev, left[0]->schema(), right[0]->schema(), left, right}).ValueOrDie();
+  // same column names and types in the same order (Acero marks its output fields nullable)
+  EXPECT_TRUE(got->schema()->field_names() == native->schema()->field_names());
+  for (int c = 0; c < native->num_columns(); ++c) EXPECT_TRUE(got->field(c)->type()->Equals(native->field(c)->type()));
+  auto gpu = SortedBy(got, {"fk", "y1", "y2"});
+  EXPECT_EQ(gpu->num_rows(), (int64_t)num_batches * batch_size);
+  for (const auto& name : native->schema()->field_names())
+    EXPECT_TRUE(native->GetColumnByName(name)->Equals(gpu->GetColumnByName(name)));
+  // a single 64-bit payload per side takes the same route
+  auto r64 = AddColumn("pk", MakeRandomRecordBatches(rng, OneColumn("x", arrow::int64()), 4, 1000), MakeIndexColumn(4, 1000).ValueOrDie());
+  auto l64 = AddColumn("fk", MakeRandomRecordBatches(rng, OneColumn("y", arrow::uint64()), 4, 1000),
+                       MakeForeignKeyColumn(rng, 1000, 4, 1000).ValueOrDie());
+  auto n64 = SortedBy(Go(join::JoinNative{l64[0]->schema(), r64[0]->schema(), l64, r64}).ValueOrDie(), {"fk", "y"});
+  auto g64 = SortedBy(Go(join::JoinGpu{*dev, l64[0]->schema(), r64[0]->schema(), l64, r64}).ValueOrDie(), {"fk", "y"});
+  for (const auto& name : n64->schema()->field_names()) EXPECT_TRUE(n64->GetColumnByName(name)->Equals(g64->GetColumnByName(name)));
+}
+
 TEST(JoinTest, MissingForeignKeyIsAnError) {
   auto left = RecordBatchOf({"fk", "y"}, {ArrayOf<U32>({1, 77}), ArrayOf<U32>({5, 6})});
   auto right = RecordBatchOf({"pk", "x"}, {ArrayOf<U32>({1, 2, 3}), ArrayOf<U32>({7, 8, 9})});

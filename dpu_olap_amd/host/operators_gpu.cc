@@ -143,37 +143,95 @@ arrow::Result<arrow::RecordBatchVector> PartitionGpu::Run() {
 // -------------------------------------------------------------------- join
 namespace join {
 
+namespace {
+
+// One column of a table as a single contiguous array (a host copy, not a computation).
+arrow::Result<std::shared_ptr<arrow::Array>> Flatten(const arrow::RecordBatchVector& batches, int column,
+                                                     const std::shared_ptr<arrow::DataType>& type) {
+  arrow::ArrayVector chunks;
+  for (const auto& b : batches) chunks.push_back(b->column(column));
+  if (chunks.empty()) return arrow::MakeEmptyArray(type);
+  if (chunks.size() == 1) return chunks.front();
+  return arrow::Concatenate(chunks);
+}
+
+}  // namespace
+
+// Gathers column `column` of `batches` at the global row ids `ids` on the GPU (olap_take).
+arrow::Result<std::shared_ptr<arrow::Array>> JoinGpu::Gather(const arrow::RecordBatchVector& batches, int column,
+                                                             const std::shared_ptr<arrow::Field>& field,
+                                                             const uint32_t* ids, uint64_t n) {
+  ARROW_ASSIGN_OR_RAISE(const int dtype, olap::DtypeOf(*field->type()));
+  ARROW_ASSIGN_OR_RAISE(auto flat, Flatten(batches, column, field->type()));
+  ARROW_ASSIGN_OR_RAISE(auto out, olap::AllocateOutputs({n}, olap::WidthOf(dtype)));
+  if (n) {
+    const void* data = flat->data()->buffers[1]->data() + flat->data()->offset * olap::WidthOf(dtype);
+    const uint64_t data_rows = (uint64_t)flat->length();
+    ARROW_RETURN_NOT_OK(system_.Check(olap_take(system_.ctx(), dtype, &data, &data_rows, &ids, &n, 1, OLAP_MEM_HOST,
+                                                out.ptrs.data(), OLAP_MEM_HOST)));
+  }
+  return olap::WrapBuffer(field->type(), (int64_t)n, out.buffers[0]);
+}
+
 arrow::Result<std::shared_ptr<arrow::Table>> JoinGpu::Run() {
   ARROW_RETURN_NOT_OK(Prepared());
   auto outer = timers_->New("outer");
   outer->Start();
   const int fk = left_schema_->GetFieldIndex("fk"), pk = right_schema_->GetFieldIndex("pk");
   if (fk < 0 || pk < 0) return arrow::Status::Invalid("left table needs a column 'fk', right table a column 'pk'");
-  // one 32-bit payload per side travels with the key (the benchmark schema {fk,y} x {pk,x})
-  if (left_schema_->num_fields() != 2 || right_schema_->num_fields() != 2)
-    return arrow::Status::NotImplemented("exactly one payload column per side");
-  const int ly = 1 - fk, rx = 1 - pk;
-  for (const auto& field : {left_schema_->field(fk), left_schema_->field(ly), right_schema_->field(pk), right_schema_->field(rx)})
+  for (const auto& field : {left_schema_->field(fk), right_schema_->field(pk)})
     if (field->type()->id() != arrow::Type::UINT32 && field->type()->id() != arrow::Type::INT32)
-      return arrow::Status::TypeError("32-bit integer join columns expected, got ", field->ToString());
+      return arrow::Status::TypeError("32-bit integer join keys expected, got ", field->ToString());
+  auto is32 = [](const arrow::Field& f) { return f.type()->id() == arrow::Type::UINT32 || f.type()->id() == arrow::Type::INT32; };
   ARROW_ASSIGN_OR_RAISE(ColumnTable lkey, olap::MakeColumnTable(left_batches_, fk));
-  ARROW_ASSIGN_OR_RAISE(ColumnTable lpay, olap::MakeColumnTable(left_batches_, ly));
   ARROW_ASSIGN_OR_RAISE(ColumnTable rkey, olap::MakeColumnTable(right_batches_, pk));
-  ARROW_ASSIGN_OR_RAISE(ColumnTable rpay, olap::MakeColumnTable(right_batches_, rx));
   const uint64_t n_left = lkey.total_rows();
-  ARROW_ASSIGN_OR_RAISE(auto out, olap::AllocateOutputs({n_left, n_left, n_left}, 4));  // fk, y, x
   auto u32pp = [](const ColumnTable& t) { return reinterpret_cast<const uint32_t* const*>(t.ptrs.data()); };
-  uint64_t out_rows = 0;
-  ARROW_RETURN_NOT_OK(system_.Check(olap_join_u32(
-      system_.ctx(), u32pp(lkey), u32pp(lpay), lkey.rows.data(), lkey.ptrs.size(), u32pp(rkey), u32pp(rpay),
-      rkey.rows.data(), rkey.ptrs.size(), OLAP_MEM_HOST, static_cast<uint32_t*>(out.ptrs[0]),
-      static_cast<uint32_t*>(out.ptrs[1]), static_cast<uint32_t*>(out.ptrs[2]), n_left, OLAP_MEM_HOST, &out_rows, &stats_)));
+  // result schema: the left columns, then every right column but the key (join_dpu.cc:314-363)
   arrow::FieldVector fields = left_schema_->fields();
-  fields.push_back(right_schema_->field(rx));
-  std::vector<std::shared_ptr<arrow::Array>> columns(3);
-  columns[fk] = olap::WrapBuffer(left_schema_->field(fk)->type(), (int64_t)out_rows, out.buffers[0]);
-  columns[ly] = olap::WrapBuffer(left_schema_->field(ly)->type(), (int64_t)out_rows, out.buffers[1]);
-  columns[2] = olap::WrapBuffer(right_schema_->field(rx)->type(), (int64_t)out_rows, out.buffers[2]);
+  for (int c = 0; c < right_schema_->num_fields(); ++c)
+    if (c != pk) fields.push_back(right_schema_->field(c));
+  std::vector<std::shared_ptr<arrow::Array>> columns;
+  uint64_t out_rows = 0;
+  ARROW_ASSIGN_OR_RAISE(auto out, olap::AllocateOutputs({n_left, n_left, n_left}, 4));
+  auto* o0 = static_cast<uint32_t*>(out.ptrs[0]);
+  auto* o1 = static_cast<uint32_t*>(out.ptrs[1]);
+  auto* o2 = static_cast<uint32_t*>(out.ptrs[2]);
+  const bool inline_payloads = left_schema_->num_fields() == 2 && right_schema_->num_fields() == 2 &&
+                               is32(*left_schema_->field(1 - fk)) && is32(*right_schema_->field(1 - pk));
+  if (inline_payloads) {
+    // the benchmark schema {fk, y} x {pk, x}: one 32-bit payload per side travels with its key
+    const int ly = 1 - fk, rx = 1 - pk;
+    ARROW_ASSIGN_OR_RAISE(ColumnTable lpay, olap::MakeColumnTable(left_batches_, ly));
+    ARROW_ASSIGN_OR_RAISE(ColumnTable rpay, olap::MakeColumnTable(right_batches_, rx));
+    ARROW_RETURN_NOT_OK(system_.Check(olap_join_u32(system_.ctx(), u32pp(lkey), u32pp(lpay), lkey.rows.data(), lkey.ptrs.size(),
+                                                    u32pp(rkey), u32pp(rpay), rkey.rows.data(), rkey.ptrs.size(), OLAP_MEM_HOST,
+                                                    o0, o1, o2, n_left, OLAP_MEM_HOST, &out_rows, &stats_)));
+    columns.resize(3);
+    columns[fk] = olap::WrapBuffer(left_schema_->field(fk)->type(), (int64_t)out_rows, out.buffers[0]);
+    columns[ly] = olap::WrapBuffer(left_schema_->field(ly)->type(), (int64_t)out_rows, out.buffers[1]);
+    columns[2] = olap::WrapBuffer(right_schema_->field(rx)->type(), (int64_t)out_rows, out.buffers[2]);
+  } else {
+    // any other schema: the join returns selection vectors (left row id, right row id of the
+    // match) and every non-key column is gathered through them -- the reference's
+    // hash_probe + take per column (join_dpu.cc:325-363)
+    ARROW_RETURN_NOT_OK(system_.Check(olap_join_u32(system_.ctx(), u32pp(lkey), nullptr, lkey.rows.data(), lkey.ptrs.size(),
+                                                    u32pp(rkey), nullptr, rkey.rows.data(), rkey.ptrs.size(), OLAP_MEM_HOST, o0,
+                                                    o1, o2, n_left, OLAP_MEM_HOST, &out_rows, &stats_)));
+    for (int c = 0; c < left_schema_->num_fields(); ++c) {
+      if (c == fk) {
+        columns.push_back(olap::WrapBuffer(left_schema_->field(fk)->type(), (int64_t)out_rows, out.buffers[0]));
+      } else {
+        ARROW_ASSIGN_OR_RAISE(auto col, Gather(left_batches_, c, left_schema_->field(c), o1, out_rows));
+        columns.push_back(std::move(col));
+      }
+    }
+    for (int c = 0; c < right_schema_->num_fields(); ++c) {
+      if (c == pk) continue;
+      ARROW_ASSIGN_OR_RAISE(auto col, Gather(right_batches_, c, right_schema_->field(c), o2, out_rows));
+      columns.push_back(std::move(col));
+    }
+  }
   outer->Stop();
   ARROW_RETURN_NOT_OK(Finish());
   return arrow::Table::Make(arrow::schema(fields), columns);

@@ -99,6 +99,11 @@ class JoinGpu : public GpuOperator {
   const olap_join_stats& Stats() const { return stats_; }
 
  private:
+  arrow::Result<std::shared_ptr<arrow::Array>> Gather(const arrow::RecordBatchVector& batches, int column,
+                                                      const std::shared_ptr<arrow::Field>& field, const uint32_t* ids,
+                                                      uint64_t n);
+
+ private:
   std::shared_ptr<arrow::Schema> left_schema_, right_schema_;
   arrow::RecordBatchVector left_batches_, right_batches_;
   olap_join_stats stats_{};

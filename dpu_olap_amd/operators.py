@@ -269,10 +269,17 @@ class JoinGpu(_Op):
     join_dpu.cc:314-363), partition-major row order (sort before comparing, as
     host/join/join_test.cc:27-38 does).  A batch is a (key, payload) pair."""
 
-    def __init__(self, system: Device, left_batches: Sequence, right_batches: Sequence):
+    def __init__(self, system: Device, left_batches: Sequence, right_batches: Sequence, select: bool = False):
+        """select=True: batches are bare key columns and the result's "y" / "x" are selection
+        vectors -- the global left row index of every result row and the global right row index
+        of its match (what kernel_hash_probe returns; gather further columns with TakeGpu)."""
         super().__init__(system)
-        self.lfk, self.ly = _columns(left_batches, 0), _columns(left_batches, 1)
-        self.rpk, self.rx = _columns(right_batches, 0), _columns(right_batches, 1)
+        self.select = select
+        if select:
+            self.lfk, self.ly, self.rpk, self.rx = list(left_batches), None, list(right_batches), None
+        else:
+            self.lfk, self.ly = _columns(left_batches, 0), _columns(left_batches, 1)
+            self.rpk, self.rx = _columns(right_batches, 0), _columns(right_batches, 1)
         self.stats: dict = {}
 
     @staticmethod
@@ -281,11 +288,12 @@ class JoinGpu(_Op):
 
     def Run(self) -> dict:
         self._need_prepare()
-        lfk, ly, rpk, rx = (self._u32(c) for c in (self.lfk, self.ly, self.rpk, self.rx))
+        lfk, rpk = self._u32(self.lfk), self._u32(self.rpk)
+        ly, rx = ([], []) if self.select else (self._u32(self.ly), self._u32(self.rx))
         lp, lrows, lmem, _ = _table(lfk)
-        lyp, _, lymem, _ = _table(ly)
         rp, rrows, rmem, _ = _table(rpk)
-        rxp, _, rxmem, _ = _table(rx)
+        lyp, _, lymem, _ = (None, None, lmem, None) if self.select else _table(ly)
+        rxp, _, rxmem, _ = (None, None, rmem, None) if self.select else _table(rx)
         mems = {m for m, c in ((lmem, lfk), (lymem, ly), (rmem, rpk), (rxmem, rx)) if c}
         if len(mems) > 1:
             raise ValueError("all join columns must live in the same memory space")

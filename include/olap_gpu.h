@@ -184,6 +184,11 @@ typedef struct {
   uint64_t missing_keys;     /* probe keys without a match */
 } olap_join_stats;
 
+/* Selection-vector form: left_y_ptrs == NULL makes out_y the GLOBAL LEFT ROW INDEX of every
+ * result row (rows numbered across the batches in order), right_x_ptrs == NULL makes out_x
+ * the global right row index of its match -- what kernel_hash_probe returns
+ * (dpu/shared/kernels/hash_probe.c:9-46) and what the host then feeds to the take kernel for
+ * every further column (host/join/join_dpu.cc:325-363). */
 int olap_join_u32(olap_ctx* ctx, const uint32_t* const* left_fk_ptrs,
                   const uint32_t* const* left_y_ptrs, const uint64_t* left_rows,
                   uint64_t n_left_batches, const uint32_t* const* right_pk_ptrs,

@@ -766,3 +766,43 @@ def test_host_operands_through_the_pinned_ring(dev, stage, threads):
     finally:
         dev.set_tuning("host_stage", 1)
         dev.set_tuning("host_copy_threads", 0)
+
+
+@pytest.mark.parametrize("space", ["host", "device"])
+def test_join_selection_vectors(dev, golden, space):
+    """olap_join_u32 with NULL payload tables: y / x come back as the global left / right row
+    index (kernel_hash_probe's selection indices); gathering through them reproduces the
+    Arrow golden join."""
+    o = _ops()
+    fk, y, pk, x = (golden[f"join_b_{k}"] for k in ("fk", "y", "pk", "x"))
+    lb = split_batches(fk, golden["join_b_left_rows"])
+    rb = split_batches(pk, golden["join_b_right_rows"])
+    if space == "device":
+        lb, rb = [dev.to_device(b) for b in lb], [dev.to_device(b) for b in rb]
+    r = o.JoinGpu(dev, lb, rb, select=True).Prepare().Run()
+    get = (lambda a: a) if space == "host" else dev.to_host
+    ofk, lrow, rrow = get(r["fk"]), get(r["y"]), get(r["x"])
+    np.testing.assert_array_equal(np.sort(lrow), np.arange(fk.size, dtype=np.uint32))   # every left row exactly once
+    np.testing.assert_array_equal(fk[lrow], ofk)
+    np.testing.assert_array_equal(pk[rrow], ofk)
+    a, b_, c = sort_rows(ofk, y[lrow], x[rrow])
+    np.testing.assert_array_equal(a, golden["join_b_out_fk"])
+    np.testing.assert_array_equal(b_, golden["join_b_out_y"])
+    np.testing.assert_array_equal(c, golden["join_b_out_x"])
+
+
+def test_join_many_short_batches_scratch_sizing(dev):
+    """24 x 50021-row batches: every batch rounds up to whole 4096-row tiles, so pass 0 has far
+    more tiles than rows / 8192 -- the histogram matrix must be sized for that."""
+    o = _ops()
+    rng = np.random.default_rng(5)
+    nb, rows = 24, 50021
+    pk = [np.arange(b * rows, (b + 1) * rows, dtype=np.uint32) for b in range(nb)]
+    x = [rng.integers(0, 1 << 32, size=rows, dtype=np.uint32) for _ in range(nb)]
+    fk = [rng.integers(0, nb * rows, size=rows, dtype=np.uint32) for _ in range(nb)]
+    y = [rng.integers(0, 1 << 32, size=rows, dtype=np.uint32) for _ in range(nb)]
+    r = o.JoinGpu(dev, list(zip(fk, y)), list(zip(pk, x))).Prepare().Run()
+    np.testing.assert_array_equal(r["x"], np.concatenate(x)[r["fk"]])
+    a, b_ = sort_rows(r["fk"], r["y"])
+    e = sort_rows(np.concatenate(fk), np.concatenate(y))
+    np.testing.assert_array_equal(a, e[0]); np.testing.assert_array_equal(b_, e[1])
