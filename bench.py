@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--radix-bits", type=int, default=-1, help="tuning: total radix bits (default auto)")
     ap.add_argument("--max-bits-per-pass", type=int, default=0, help="tuning: fan-out cap per pass (default 10)")
     ap.add_argument("--scatter-variant", type=int, default=0, help="tuning: 0 write-combining, 1 tile-staged")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=INT", help="olap_set_tuning knob for A/B runs (e.g. claim_mode=0)")
     ap.add_argument("--cpu-sf", type=int, default=0, help="scale factor of the bounded CPU sample (default: auto)")
     return ap.parse_args()
 
@@ -122,6 +123,9 @@ def main():
     ops = GpuLocalOps(ctx, device)
     ctx.join_configure(args.radix_bits, args.max_bits_per_pass)
     ctx.set_tuning("scatter_variant", args.scatter_variant)
+    for kv in args.tune:
+        k, _, v = kv.partition("=")
+        ctx.set_tuning(k, int(v))
 
     # ---- workload size
     free = info["free_mem"]

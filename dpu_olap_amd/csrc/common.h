@@ -84,6 +84,7 @@ struct olap_ctx {
   int direct_table = 1;    // collision-free direct-address LDS table when <= 14 hash bits remain (0: always probe)
   int wc_geometry = 2;     // 2: passes of <= 512 buckets use 512-thread workgroups on 4096-tuple tiles, two per CU
   int capacity_mode = 1;   // last radix pass without histogram (fixed-capacity regions + exact fallback)
+  int claim_mode = 1;      // pass 0 of a two-pass plan without histogram (claimed allotments): 0 off, 1 auto, 2 always
   int hash_skip_bits = 0;  // top hash bits already fixed by an upstream owner split
 
   // OLAP_MEM_HOST operands

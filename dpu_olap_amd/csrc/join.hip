@@ -58,6 +58,14 @@ struct PassSrc {
   // SRC_TUPLES, pre-split input: block k of the grid reads tuples [blk_range[2k], blk_range[2k+1])
   // (one chunk per sender of an exchanged segment) instead of an even share of its segment
   const uint64_t* blk_range;
+  // SRC_TUPLES, input written by the claiming scatter (k_part_scatter_claim): segment k is
+  // [k * seg_cap, k * seg_cap + min(seg_cnt[k], seg_cap)) and holds filler tuples, which are
+  // recognised by their hash: a real tuple of segment k has ((hash >> chk_shift) & chk_mask)
+  // == (k & chk_mask)
+  const uint32_t* seg_cnt;
+  uint32_t seg_cap;
+  uint32_t chk_shift;
+  uint32_t chk_mask;  // 0: every tuple in range is real
 };
 
 struct TileRange {
@@ -87,8 +95,13 @@ __device__ __forceinline__ TileRange block_tiles(const PassSrc& s) {
       return r;
     }
     const uint32_t j = blockIdx.x - r.seg * s.blocks_per_seg;
-    r.lo = s.seg_off[r.seg];
-    r.hi = s.seg_off[r.seg + 1];
+    if (s.seg_cnt) {
+      r.lo = (uint64_t)r.seg * s.seg_cap;
+      r.hi = r.lo + min(s.seg_cnt[r.seg], s.seg_cap);
+    } else {
+      r.lo = s.seg_off[r.seg];
+      r.hi = s.seg_off[r.seg + 1];
+    }
     r.a = r.lo & ~1ull;
     const uint64_t tiles = (r.hi - r.a + TILE - 1) / TILE;
     const uint64_t q = (tiles + s.blocks_per_seg - 1) / s.blocks_per_seg;
@@ -479,18 +492,21 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_wc(PassSrc s, uint32_t s
     // (2) bucket + rank of every tuple
     uint32_t br[kWTPT];
     constexpr uint32_t kFull = (1u << kWTPT) - 1u;
-    if (mask == kFull) {  // whole tile valid (all but the edge tiles): no per-tuple predication
+    if (mask == kFull && !s.chk_mask) {  // whole tile valid (all but the edge tiles): no per-tuple predication
 #pragma unroll
       for (int i = 0; i < kWTPT; ++i) {
         const uint32_t b = (wang_hash(key[i]) >> shift) & (F - 1);
         br[i] = (b << 16) | atomicAdd(&cl[b], 1u);
       }
     } else {
+      const uint32_t expect = r.seg & s.chk_mask;
 #pragma unroll
       for (int i = 0; i < kWTPT; ++i) {
         br[i] = 0;
+        const uint32_t h = wang_hash(key[i]);
+        if (((h >> s.chk_shift) & s.chk_mask) != expect) mask &= ~(1u << i);  // a filler of the claiming scatter
         if (mask & (1u << i)) {
-          const uint32_t b = (wang_hash(key[i]) >> shift) & (F - 1);
+          const uint32_t b = (h >> shift) & (F - 1);
           br[i] = (b << 16) | atomicAdd(&cl[b], 1u);
         }
       }
@@ -621,6 +637,220 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_wc(PassSrc s, uint32_t s
       co.cnt[(uint64_t)r.seg * F + b_own] = (uint32_t)count;
       co.dense[(uint64_t)r.seg * F + b_own] = r.lo + pre;
     }
+  }
+}
+
+// Claiming scatter: a pass WITHOUT a histogram that any number of workgroups can run on
+// the same buckets.  Bucket (seg, b) owns the fixed region [p * cap, (p + 1) * cap),
+// p = seg * F + b.  A workgroup writes a bucket's lines into an allotment of kClaimChunk
+// tuples it claimed with ONE global atomic on the bucket's cursor (2^32 rows -> 32 M atomics,
+// spread over the buckets), and claims the next when it runs out -- a tile's flush may
+// straddle the old and the new allotment.  At the end the unused rest of each workgroup's
+// last allotment is padded with filler tuples: a key of ANOTHER bucket, which the consumer
+// pass recognises by its hash (PassSrc::chk_*), so regions need no per-chunk bookkeeping.
+// A region that would outgrow cap raises *overflow (the host reruns with exact passes).
+struct ClaimOut {
+  uint32_t cap;      // tuples per region, multiple of kClaimChunk
+  uint32_t* cursor;  // [n_seg * F], zeroed before the launch: tuples claimed per region
+  unsigned long long* overflow;
+};
+constexpr uint32_t kClaimChunk = 128;
+
+template <int SRC, int BLOCK, int TILE>
+__global__ __launch_bounds__(BLOCK) void k_part_scatter_claim(PassSrc s, uint32_t shift, uint32_t fbits, uint2* out,
+                                                                ClaimOut co) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using LDS = WcLds<8, BLOCK, TILE>;
+  constexpr int kWTPT = TILE / BLOCK;
+  constexpr int kLine = 8, kRes = 7;
+  uint2* stage = (uint2*)(smem + LDS::kStage);
+  uint2* res = (uint2*)(smem + LDS::kResOff);
+  // bm[b]: x = vstart | lstart << 16 (this tile), y = tuple offset of the bucket's next line in
+  // its region, z = offset of the allotment claimed in this tile, w = tuples left in the
+  // current allotment | residue count << 16
+  uint4* bm = (uint4*)(smem + LDS::kBm);
+  uint32_t* cl = (uint32_t*)(smem + LDS::kCl);
+  uint16_t* l2b = (uint16_t*)(smem + LDS::kL2b);
+  uint64_t* wtot = (uint64_t*)(smem + ((LDS::kWtot + 15) / 16) * 16);
+  const uint32_t F = 1u << fbits;
+  const TileRange r = block_tiles<SRC, TILE>(s);
+  const unsigned lane = lane_id();
+  const unsigned wave = threadIdx.x / kWave;
+  const uint32_t b_own = threadIdx.x;
+  const bool owner = b_own < F;
+  const uint64_t p_own = (uint64_t)r.seg * F + b_own;
+  if (owner) {
+    bm[b_own] = make_uint4(0u, 0u, 0u, 0u);
+    cl[b_own] = 0;
+  }
+  __syncthreads();
+  uint32_t key[kWTPT], pay[kWTPT], nkey[kWTPT], npay[kWTPT];
+  uint32_t mask = 0, nmask = 0;
+  ColsCursor cur;
+  if (r.t0 < r.t1) mask = load_tile<SRC, BLOCK, true, TILE>(s, r, r.t0, cur, key, pay);
+  for (uint64_t tile = r.t0; tile < r.t1; ++tile) {
+    uint32_t br[kWTPT];
+    const uint32_t expect = r.seg & s.chk_mask;
+#pragma unroll
+    for (int i = 0; i < kWTPT; ++i) {
+      br[i] = 0;
+      const uint32_t h = wang_hash(key[i]);
+      if (((h >> s.chk_shift) & s.chk_mask) != expect) mask &= ~(1u << i);
+      if (mask & (1u << i)) {
+        const uint32_t b = (h >> shift) & (F - 1);
+        br[i] = (b << 16) | atomicAdd(&cl[b], 1u);
+      }
+    }
+    __syncthreads();
+    uint32_t c = 0, c_app = 0, rr = 0, f = 0, pos = 0, rem = 0, pos_new = 0, claimed = 0;
+    if (owner) {
+      c = cl[b_own];
+      const uint4 m = bm[b_own];
+      pos = m.y;
+      rem = m.w & 0xFFFFu;
+      rr = (m.w >> 16) & 15u;
+      c_app = c;
+      f = (rr + c) & ~(uint32_t)(kLine - 1);
+      if (f > rem) {
+        const uint32_t need = (f - rem + kClaimChunk - 1) / kClaimChunk * kClaimChunk;
+        const uint32_t got = atomicAdd(&co.cursor[p_own], need);
+        if ((uint64_t)got + need > co.cap) {  // region full: drop this tile's tuples of the bucket, report
+          atomicAdd(co.overflow, 1ull);
+          c_app = 0;
+          f = 0;
+        } else {
+          pos_new = got;
+          claimed = need;
+        }
+      }
+    }
+    const uint64_t pair = (uint64_t)c | ((uint64_t)f << 32);
+    uint64_t incl = pair;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+      const uint64_t yv = __shfl_up(incl, o, kWave);
+      if ((int)lane >= o) incl += yv;
+    }
+    if (lane == kWave - 1) wtot[wave] = incl;
+    __syncthreads();
+    uint64_t pre = incl - pair, tot = 0;
+#pragma unroll 1
+    for (int w = 0; w < BLOCK / kWave; ++w) {
+      const uint64_t t = wtot[w];
+      if ((unsigned)w < wave) pre += t;
+      tot += t;
+    }
+    const uint32_t lstart = (uint32_t)pre, vstart = (uint32_t)(pre >> 32);
+    const uint32_t V = (uint32_t)(tot >> 32);
+    if (owner) {
+      bm[b_own] = make_uint4(vstart | (lstart << 16), pos, pos_new, rem | (rr << 16));
+      cl[b_own] = lstart;
+      for (uint32_t q = 0; q < f / kLine; ++q) l2b[vstart / kLine + q] = (uint16_t)b_own;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < kWTPT; ++i) {
+      if (mask & (1u << i)) stage[cl[br[i] >> 16] + (br[i] & 0xFFFFu)] = make_uint2(key[i], pay[i]);
+    }
+    nmask = 0;
+    if (tile + 1 < r.t1) nmask = load_tile<SRC, BLOCK, true, TILE>(s, r, tile + 1, cur, nkey, npay);
+    __syncthreads();
+    // copy-out: 4 consecutive lanes write one aligned 64-byte line; a bucket's lines go to the
+    // rest of its old allotment first, then to the one claimed in this tile
+#pragma unroll 1
+    for (uint32_t v = threadIdx.x * 2; v < V; v += BLOCK * 2) {
+      const uint32_t b = l2b[v / kLine];
+      const uint4 m = bm[b];
+      const uint32_t j = v - (m.x & 0xFFFFu);  // even
+      const uint32_t ls = m.x >> 16, r_old = (m.w >> 16) & 15u, rem_old = m.w & 0xFFFFu;
+      const uint2 t0 = j < r_old ? res[b * kRes + j] : stage[ls + (j - r_old)];
+      const uint2 t1 = j + 1 < r_old ? res[b * kRes + j + 1] : stage[ls + (j + 1 - r_old)];
+      const uint32_t off = j < rem_old ? m.y + j : m.z + (j - rem_old);
+      *(uint4*)(out + ((uint64_t)r.seg * F + b) * co.cap + off) = make_uint4(t0.x, t0.y, t1.x, t1.y);
+    }
+    __syncthreads();
+    if (owner) {
+      uint32_t r_new;
+      if (f) {
+        const uint32_t nf = f - rr;
+        r_new = rr + c_app - f;
+        for (uint32_t q = 0; q < r_new; ++q) res[b_own * kRes + q] = stage[lstart + nf + q];
+        if (f > rem) {
+          pos = pos_new + (f - rem);
+          rem = claimed - (f - rem);
+        } else {
+          pos += f;
+          rem -= f;
+        }
+      } else {
+        for (uint32_t q = 0; q < c_app; ++q) res[b_own * kRes + rr + q] = stage[lstart + q];
+        r_new = rr + c_app;
+      }
+      bm[b_own].y = pos;
+      bm[b_own].w = rem | (r_new << 16);
+      cl[b_own] = 0;
+    }
+    __syncthreads();
+    mask = nmask;
+#pragma unroll
+    for (int i = 0; i < kWTPT; ++i) {
+      key[i] = nkey[i];
+      pay[i] = npay[i];
+    }
+  }
+  // tail: the residue goes out as one padded line, the rest of the allotment as fillers
+  if (owner) {
+    const uint4 m = bm[b_own];
+    uint32_t pos = m.y, rem = m.w & 0xFFFFu;
+    const uint32_t rr = (m.w >> 16) & 15u;
+    uint32_t filler = 0;
+    while (((wang_hash(filler) >> shift) & (F - 1)) == b_own) ++filler;  // a key of another bucket
+    uint2* region = out + p_own * co.cap;
+    bool ok = true;
+    if (rr && rem == 0) {
+      const uint32_t got = atomicAdd(&co.cursor[p_own], kClaimChunk);
+      if ((uint64_t)got + kClaimChunk > co.cap) {
+        atomicAdd(co.overflow, 1ull);
+        ok = false;
+      } else {
+        pos = got;
+        rem = kClaimChunk;
+      }
+    }
+    if (ok) {
+      if (rr) {
+        for (uint32_t j = 0; j < (uint32_t)kLine; ++j) region[pos + j] = j < rr ? res[b_own * kRes + j] : make_uint2(filler, 0u);
+        pos += kLine;
+        rem -= kLine;
+      }
+      for (uint32_t q = 0; q < rem; q += 2) *(uint4*)(region + pos + q) = make_uint4(filler, 0u, filler, 0u);
+    }
+  }
+}
+
+// dense[p] = sum of cnt[0 .. p): the dense numbering of a capacity layout whose input had
+// fillers (the scatter cannot know its segment's dense start then).  One workgroup.
+__global__ __launch_bounds__(1024) void k_dense_scan(const uint32_t* cnt, uint64_t n, uint64_t* dense) {
+  __shared__ uint64_t s_part[1024];
+  const uint64_t per = (n + 1023) / 1024;
+  const uint64_t lo = min(n, threadIdx.x * per), hi = min(n, lo + per);
+  uint64_t sum = 0;
+  for (uint64_t i = lo; i < hi; ++i) sum += cnt[i];
+  s_part[threadIdx.x] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint64_t run = 0;
+    for (int i = 0; i < 1024; ++i) {
+      const uint64_t v = s_part[i];
+      s_part[i] = run;
+      run += v;
+    }
+  }
+  __syncthreads();
+  uint64_t run = s_part[threadIdx.x];
+  for (uint64_t i = lo; i < hi; ++i) {
+    dense[i] = run;
+    run += cnt[i];
   }
 }
 
@@ -1000,6 +1230,7 @@ static uint64_t side_scratch_bytes(const olap_ctx* ctx, uint64_t rows, uint64_t 
     n_seg *= F;
   }
   bytes += align_up(n_seg * 4, 256) + align_up(n_seg * 8, 256);  // capacity-layout tables
+  bytes += align_up((1ull << plan.bits[0]) * 4, 256);               // claim cursors
   return bytes + 4096;
 }
 
@@ -1025,6 +1256,28 @@ static bool capacity_eligible(const olap_ctx* ctx, uint64_t rows, const PassPlan
   return n_seg_last >= (uint64_t)ctx->compute_units && rows / P >= 512;
 }
 
+// Region size of the claiming scatter: the average bucket, 8 sigma of slack (uniform hash),
+// and what the workgroups may leave unused in their last allotments.  0: does not fit 32 bits.
+static uint32_t claim_cap(const olap_ctx* ctx, uint64_t rows, uint64_t F) {
+  const uint64_t kb = (uint64_t)ctx->compute_units * 2 > 256 ? (uint64_t)ctx->compute_units * 2 : 256;  // workgroups of pass 0
+  const uint64_t avg = (rows + F - 1) / F;
+  uint64_t sd = 1;
+  while (sd * sd < avg) ++sd;
+  const uint64_t cap = align_up(avg + avg / 64 + 8 * sd + (kb + 2) * kClaimChunk, kClaimChunk);
+  return cap >= (1ull << 32) ? 0u : (uint32_t)cap;
+}
+
+// Pass 0 of a two-pass plan may run as a claiming scatter (no histogram) when the last pass
+// uses the capacity layout; automatic when the padding it costs stays below 1/16 of the rows.
+static bool claim_eligible(const olap_ctx* ctx, uint64_t rows, const PassPlan& plan, bool capm) {
+  if (!ctx->claim_mode || !capm || plan.passes != 2 || ctx->scatter_variant != 0 || ctx->line16) return false;
+  const uint64_t F = 1ull << plan.bits[0];
+  if (!claim_cap(ctx, rows, F)) return false;
+  if (ctx->claim_mode >= 2) return true;
+  const uint64_t kb = (uint64_t)ctx->compute_units * 2 > 256 ? (uint64_t)ctx->compute_units * 2 : 256;
+  return kb * kClaimChunk * F <= rows / 16;
+}
+
 constexpr int kW2Block = 512;   // geometry 2 of the write-combining scatter: two workgroups per CU
 constexpr int kW2Tile = 4096;
 constexpr uint32_t kWc2Lds = WcLds<8, kW2Block, kW2Tile>::kBytes;
@@ -1043,7 +1296,7 @@ static uint32_t pass0_tile(const olap_ctx* ctx, const PassPlan& plan) {
 static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, const uint2* tuple_in,
                           uint64_t tuple_n, const PassPlan& plan, uint32_t skip_bits, uint2* tmp0, uint2* tmp1,
                           uint2* final_tuples, bool capm, unsigned long long* d_overflow, SideOut* so,
-                          const Presplit* pre = nullptr) {
+                          const Presplit* pre = nullptr, bool claim = false) {
   const uint64_t rows = tuple_in ? tuple_n : cs.view.total_rows;
   PassSrc src{};
   uint64_t n_seg = 1;
@@ -1111,6 +1364,15 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
   OLAP_WC2_ATTR(SRC_TUPLES, false);
   OLAP_WC2_ATTR(SRC_TUPLES, true);
 #undef OLAP_WC2_ATTR
+#define OLAP_CLAIM_ATTR(SRCV, BLOCKV, TILEV, LDSV)                                                                 \
+  OLAP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_scatter_claim<SRCV, BLOCKV, TILEV>),     \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDSV))
+  OLAP_CLAIM_ATTR(SRC_COLS, kW2Block, kW2Tile, kWc2Lds);
+  OLAP_CLAIM_ATTR(SRC_TUPLES, kW2Block, kW2Tile, kWc2Lds);
+  OLAP_CLAIM_ATTR(SRC_COLS, kWBlock, kPTile, WcLds<8>::kBytes);
+  OLAP_CLAIM_ATTR(SRC_TUPLES, kWBlock, kPTile, WcLds<8>::kBytes);
+#undef OLAP_CLAIM_ATTR
+  bool claimed_input = false;  // the current input was written by the claiming scatter
   const bool wc = ctx->scatter_variant == 0;  // write-combining scatter
   for (int i = 0; i < plan.passes; ++i) {
     const uint32_t fbits = plan.bits[i];
@@ -1142,6 +1404,38 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
       src.blk_range = ranged ? pre_ranges : nullptr;
     }
     if (blocks > 0x7FFFFFFFull) return ctx->fail(OLAP_ERR_INVALID, "partition grid too large");
+    if (claim && i == 0 && plan.passes == 2 && wc && !pre) {  // claiming scatter: no histogram
+      const uint32_t ccap = claim_cap(ctx, rows, F);
+      uint32_t* cursor = (uint32_t*)ws_alloc(ctx, F * 4);
+      if (!cursor || !ccap) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (claim cursors)");
+      OLAP_HIP(ctx, hipMemsetAsync(cursor, 0, F * 4, ctx->stream));
+      {
+        PhaseScope ps(ctx, PH_PART_SCATTER);
+        const ClaimOut co{ccap, cursor, d_overflow};
+        if (g2 && cols)
+          hipLaunchKernelGGL((k_part_scatter_claim<SRC_COLS, kW2Block, kW2Tile>), dim3((unsigned)blocks), dim3(kW2Block), kWc2Lds,
+                             ctx->stream, src, shift, fbits, out, co);
+        else if (g2)
+          hipLaunchKernelGGL((k_part_scatter_claim<SRC_TUPLES, kW2Block, kW2Tile>), dim3((unsigned)blocks), dim3(kW2Block), kWc2Lds,
+                             ctx->stream, src, shift, fbits, out, co);
+        else if (cols)
+          hipLaunchKernelGGL((k_part_scatter_claim<SRC_COLS, kWBlock, kPTile>), dim3((unsigned)blocks), dim3(kWBlock),
+                             WcLds<8>::kBytes, ctx->stream, src, shift, fbits, out, co);
+        else
+          hipLaunchKernelGGL((k_part_scatter_claim<SRC_TUPLES, kWBlock, kPTile>), dim3((unsigned)blocks), dim3(kWBlock),
+                             WcLds<8>::kBytes, ctx->stream, src, shift, fbits, out, co);
+        OLAP_HIP(ctx, hipGetLastError());
+      }
+      src.seg_cnt = cursor;  // the next pass reads regions of `ccap` tuples and skips the fillers
+      src.seg_cap = ccap;
+      src.chk_shift = shift;
+      src.chk_mask = (uint32_t)F - 1;
+      claimed_input = true;
+      in_tuples = out;
+      seg_in = nullptr;
+      n_seg *= F;
+      continue;
+    }
     if (capm && i == plan.passes - 1 && !src.blk_range) {  // capacity layout: scatter only
       so->cap = region_cap(rows, n_seg * F);
       so->cnt = (uint32_t*)ws_alloc(ctx, n_seg * F * 4);
@@ -1162,8 +1456,13 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
                            WcLds<8>::kBytes, ctx->stream, src, shift, fbits, (const uint32_t*)nullptr,
                            (const uint64_t*)nullptr, out, co);
       OLAP_HIP(ctx, hipGetLastError());
+      if (claimed_input) {  // the segments' dense starts were unknown to the scatter: number the partitions now
+        hipLaunchKernelGGL(k_dense_scan, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t*)so->cnt, n_seg * F, so->dense);
+        OLAP_HIP(ctx, hipGetLastError());
+      }
       return OLAP_OK;
     }
+    if (claimed_input) return ctx->fail(OLAP_ERR_INVALID, "internal: claimed input needs a capacity-layout consumer");
     uint32_t* hist = (uint32_t*)ws_alloc(ctx, blocks * F * 4);
     uint64_t* seg_out = (uint64_t*)ws_alloc(ctx, (n_seg * F + 1) * 8);
     if (!hist || !seg_out) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (partition pass %d)", i);
@@ -1280,11 +1579,16 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
   const bool rcap = allow_capacity && capacity_eligible(ctx, NR, plan, pre_bits);
   const uint64_t lt_tuples = lcap ? (uint64_t)P * region_cap(NL, P) : NL;
   const uint64_t rt_tuples = rcap ? (uint64_t)P * region_cap(NR, P) : NR;
+  const bool lclaim = !in.l_pre && claim_eligible(ctx, NL, plan, lcap);
+  const bool rclaim = !in.r_pre && claim_eligible(ctx, NR, plan, rcap);
+  uint64_t tmp_tuples = maxN;  // pass-0 output: dense, or the claiming scatter's padded regions
+  if (lclaim) tmp_tuples = std::max<uint64_t>(tmp_tuples, ((uint64_t)claim_cap(ctx, NL, 1ull << plan.bits[0])) << plan.bits[0]);
+  if (rclaim) tmp_tuples = std::max<uint64_t>(tmp_tuples, ((uint64_t)claim_cap(ctx, NR, 1ull << plan.bits[0])) << plan.bits[0]);
   const bool l_pay = ly != nullptr, r_pay = rx != nullptr;  // null payload: the tuple carries its global row index
   uint64_t need = column_set_bytes(lrows, lnb, l_pay ? 2 : 1, eb, in_mem) + column_set_bytes(rrows, rnb, r_pay ? 2 : 1, eb, in_mem) +
                   side_scratch_bytes(ctx, NL, lnb, plan, in.l_pre) + side_scratch_bytes(ctx, NR, rnb, plan, in.r_pre) +
                   align_up((lt_tuples + 2) * 8, 256) + align_up((rt_tuples + 2) * 8, 256) + 8192;
-  if (plan.passes >= 2) need += align_up((maxN + 2) * 8, 256);
+  if (plan.passes >= 2) need += align_up((tmp_tuples + 2) * 8, 256);
   if (plan.passes >= 3) need += align_up((maxN + 2) * 8, 256);
   if (out_mem == OLAP_MEM_HOST) need += 3 * align_up(NL * 4 + 4, 256);
   uint64_t pin = (lnb + rnb + 2) * 8 * 8 + 8192;
@@ -1294,7 +1598,7 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
   ColumnSet lcs, rcs;
   if (!in.l_tuples) OLAP_TRY(build_column_set(ctx, lcols, l_pay ? 2 : 1, eb, lrows, lnb, in_mem, pass0_tile(ctx, plan), &lcs));
   if (!in.r_tuples) OLAP_TRY(build_column_set(ctx, rcols, r_pay ? 2 : 1, eb, rrows, rnb, in_mem, pass0_tile(ctx, plan), &rcs));
-  uint2* tmp0 = plan.passes >= 2 ? (uint2*)ws_alloc(ctx, (maxN + 2) * 8) : nullptr;
+  uint2* tmp0 = plan.passes >= 2 ? (uint2*)ws_alloc(ctx, (tmp_tuples + 2) * 8) : nullptr;
   uint2* tmp1 = plan.passes >= 3 ? (uint2*)ws_alloc(ctx, (maxN + 2) * 8) : nullptr;
   uint2* Lt = (uint2*)ws_alloc(ctx, (lt_tuples + 2) * 8);
   uint2* Rt = (uint2*)ws_alloc(ctx, (rt_tuples + 2) * 8);
@@ -1310,9 +1614,9 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
   OLAP_HIP(ctx, hipMemsetAsync(d_cnt, 0, 40, ctx->stream));
   SideOut lso, rso;
   OLAP_TRY(partition_side(ctx, lcs, l_pay, in.l_tuples, NL, plan, (uint32_t)ctx->hash_skip_bits, tmp0, tmp1, Lt, lcap,
-                          d_cnt + 4, &lso, in.l_pre));
+                          d_cnt + 4, &lso, in.l_pre, lclaim));
   OLAP_TRY(partition_side(ctx, rcs, r_pay, in.r_tuples, NR, plan, (uint32_t)ctx->hash_skip_bits, tmp0, tmp1, Rt, rcap,
-                          d_cnt + 4, &rso, in.r_pre));
+                          d_cnt + 4, &rso, in.r_pre, rclaim));
   {
     PhaseScope ps(ctx, PH_JOIN_PROBE);
     uint64_t grid = (uint64_t)ctx->compute_units * 8;
@@ -1429,6 +1733,11 @@ int olap_set_tuning(olap_ctx* ctx, const char* key, int value) {
   }
   if (!std::strcmp(key, "take_variant")) {
     ctx->take_variant = value;
+    return OLAP_OK;
+  }
+  if (!std::strcmp(key, "claim_mode")) {
+    if (value < 0 || value > 2) return ctx->fail(OLAP_ERR_INVALID, "claim_mode must be 0 (off), 1 (auto) or 2 (always)");
+    ctx->claim_mode = value;
     return OLAP_OK;
   }
   if (!std::strcmp(key, "host_stage")) {

@@ -806,3 +806,57 @@ def test_join_many_short_batches_scratch_sizing(dev):
     a, b_ = sort_rows(r["fk"], r["y"])
     e = sort_rows(np.concatenate(fk), np.concatenate(y))
     np.testing.assert_array_equal(a, e[0]); np.testing.assert_array_equal(b_, e[1])
+
+
+@pytest.mark.parametrize("shape", ["uniform", "skew", "tuples", "ragged"])
+def test_join_claiming_first_pass(dev, shape):
+    """Pass 0 as a claiming scatter (no histogram; allotments claimed with atomics, fillers
+    skipped by the next pass), forced at a size where it would not switch on by itself.
+    uniform: digest + partition-major order; skew: regions overflow -> exact rerun; tuples:
+    the zipped-tuple entry point; ragged: odd batch lengths (partial tiles)."""
+    import torch
+    o = _ops()
+    from dpu_olap_amd import datagen as dg
+    from dpu_olap_amd.dist_join import GpuLocalOps
+    rows, sf = (2 << 20, 64) if shape != "ragged" else ((2 << 20) - 12345, 61)
+    n = sf * rows
+    cols = {k: dev.empty(n, "uint32") for k in ("fk", "y", "pk", "x", "exp")}
+    dev.gen_fk_u32(cols["fk"].ptr, n, dg.SEED, dg.STREAM_FK, 0, *((n, 1024) if shape == "skew" else (rows, rows)))
+    dev.gen_uniform_u32(cols["y"].ptr, n, dg.SEED, dg.STREAM_Y, 0)
+    dev.gen_index_u32(cols["pk"].ptr, n, 0)
+    dev.gen_uniform_u32(cols["x"].ptr, n, dg.SEED, dg.STREAM_X, 0)
+    dev.gen_uniform_u32_at(cols["exp"].ptr, cols["fk"].ptr, n, dg.SEED, dg.STREAM_X)
+    expect = dev.checksum_rows3_u32(cols["fk"].ptr, cols["y"].ptr, cols["exp"].ptr, n)
+    batch = lambda c, b: o.DeviceArray(cols[c].ptr + 4 * b * rows, rows, "uint32")
+    dev.set_tuning("claim_mode", 2)
+    try:
+        if shape == "tuples":
+            device = torch.device("cuda", 0)
+            ops = GpuLocalOps(dev, device)
+            tl = torch.empty(n, dtype=torch.int64, device=device)
+            tr = torch.empty(n, dtype=torch.int64, device=device)
+            dev.partition_tuples_u32([batch("fk", b).ptr for b in range(sf)], [batch("y", b).ptr for b in range(sf)], [rows] * sf,
+                                     1, 2, tl.data_ptr(), n)
+            dev.partition_tuples_u32([batch("pk", b).ptr for b in range(sf)], [batch("x", b).ptr for b in range(sf)], [rows] * sf,
+                                     1, 2, tr.data_ptr(), n)
+            ofk, oy, ox, stats = ops.join_tuples(tl, tr, 0)
+            got = dev.checksum_rows3_u32(ofk.data_ptr(), oy.data_ptr(), ox.data_ptr(), ofk.numel())
+            assert ofk.numel() == n and stats["missing_keys"] == 0
+        else:
+            j = o.JoinGpu(dev, [(batch("fk", b), batch("y", b)) for b in range(sf)],
+                          [(batch("pk", b), batch("x", b)) for b in range(sf)]).Prepare()
+            out = j.Run()
+            assert out["fk"].rows == n
+            got = dev.checksum_rows3_u32(out["fk"].ptr, out["y"].ptr, out["x"].ptr, n)
+            if shape == "uniform":
+                fk = dev.to_host(out["fk"])
+                part = oracle.wang_hash_np(fk) >> np.uint32(32 - sum(j.stats["radix_bits"]))
+                assert (np.diff(part.astype(np.int64)) >= 0).all()
+                assert "partition-hist" not in j.Timers() or j.Timers()["partition-hist"] == 0
+            for c in out.values():
+                dev.release(o.DeviceArray(c.ptr, 0))
+    finally:
+        dev.set_tuning("claim_mode", 1)
+    assert got == expect
+    for c in cols.values():
+        dev.release(o.DeviceArray(c.ptr, 0))
