@@ -445,6 +445,9 @@ struct CapOut {
   uint32_t* cnt;      // [n_seg * F]
   uint64_t* dense;    // [n_seg * F]
   unsigned long long* overflow;
+  uint64_t* seg_total;  // non-null: the input had fillers, so the segment's dense start is unknown here --
+                        // dense[] receives the start inside the segment, seg_total[seg] the segment's
+                        // tuple count, and k_dense_fix adds the segment bases afterwards
 };
 
 template <int SRC, bool CAPM, int LINE, int BLOCK = kWBlock, int TILE = kPTile>
@@ -635,7 +638,12 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_wc(PassSrc s, uint32_t s
     for (unsigned w = 0; w < wave; ++w) pre += wtot[w];
     if (owner) {
       co.cnt[(uint64_t)r.seg * F + b_own] = (uint32_t)count;
-      co.dense[(uint64_t)r.seg * F + b_own] = r.lo + pre;
+      co.dense[(uint64_t)r.seg * F + b_own] = (co.seg_total ? 0 : r.lo) + pre;
+    }
+    if (co.seg_total && threadIdx.x == 0) {
+      uint64_t total = 0;
+      for (int w = 0; w < BLOCK / kWave; ++w) total += wtot[w];
+      co.seg_total[r.seg] = total;
     }
   }
 }
@@ -828,30 +836,18 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_claim(PassSrc s, uint32_
   }
 }
 
-// dense[p] = sum of cnt[0 .. p): the dense numbering of a capacity layout whose input had
-// fillers (the scatter cannot know its segment's dense start then).  One workgroup.
-__global__ __launch_bounds__(1024) void k_dense_scan(const uint32_t* cnt, uint64_t n, uint64_t* dense) {
-  __shared__ uint64_t s_part[1024];
-  const uint64_t per = (n + 1023) / 1024;
-  const uint64_t lo = min(n, threadIdx.x * per), hi = min(n, lo + per);
-  uint64_t sum = 0;
-  for (uint64_t i = lo; i < hi; ++i) sum += cnt[i];
-  s_part[threadIdx.x] = sum;
+// Second half of the dense numbering when the input had fillers: adds to dense[seg * F + b]
+// (start inside the segment) the tuples of all earlier segments.  One workgroup per segment.
+__global__ __launch_bounds__(1024) void k_dense_fix(const uint64_t* seg_total, uint32_t F, uint64_t* dense) {
+  __shared__ uint64_t s_wave[16];
+  uint64_t part = 0;
+  for (uint32_t i = threadIdx.x; i < blockIdx.x; i += 1024) part += seg_total[i];
+  part = wave_reduce_add(part);
+  if (lane_id() == 0) s_wave[threadIdx.x / kWave] = part;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    uint64_t run = 0;
-    for (int i = 0; i < 1024; ++i) {
-      const uint64_t v = s_part[i];
-      s_part[i] = run;
-      run += v;
-    }
-  }
-  __syncthreads();
-  uint64_t run = s_part[threadIdx.x];
-  for (uint64_t i = lo; i < hi; ++i) {
-    dense[i] = run;
-    run += cnt[i];
-  }
+  uint64_t base = 0;
+  for (int w = 0; w < 1024 / kWave; ++w) base += s_wave[w];
+  for (uint32_t b = threadIdx.x; b < F; b += 1024) dense[(uint64_t)blockIdx.x * F + b] += base;
 }
 
 // ------------------------------------------------------------ build + probe
@@ -1230,7 +1226,7 @@ static uint64_t side_scratch_bytes(const olap_ctx* ctx, uint64_t rows, uint64_t 
     n_seg *= F;
   }
   bytes += align_up(n_seg * 4, 256) + align_up(n_seg * 8, 256);  // capacity-layout tables
-  bytes += align_up((1ull << plan.bits[0]) * 4, 256);               // claim cursors
+  bytes += align_up((1ull << plan.bits[0]) * 4, 256) + align_up((1ull << plan.bits[0]) * 8, 256);  // claim cursors, segment totals
   return bytes + 4096;
 }
 
@@ -1442,7 +1438,12 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
       so->dense = (uint64_t*)ws_alloc(ctx, n_seg * F * 8);
       if (!so->cnt || !so->dense) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (capacity tables)");
       PhaseScope ps(ctx, PH_PART_SCATTER);
-      CapOut co{so->cap, so->cnt, so->dense, d_overflow};
+      uint64_t* seg_total = nullptr;
+      if (claimed_input) {
+        seg_total = (uint64_t*)ws_alloc(ctx, n_seg * 8);
+        if (!seg_total) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (segment totals)");
+      }
+      CapOut co{so->cap, so->cnt, so->dense, d_overflow, seg_total};
       if (g2)
         hipLaunchKernelGGL((k_part_scatter_wc<SRC_TUPLES, true, 8, kW2Block, kW2Tile>), dim3((unsigned)blocks), dim3(kW2Block),
                            kWc2Lds, ctx->stream, src, shift, fbits, (const uint32_t*)nullptr,
@@ -1457,7 +1458,8 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
                            (const uint64_t*)nullptr, out, co);
       OLAP_HIP(ctx, hipGetLastError());
       if (claimed_input) {  // the segments' dense starts were unknown to the scatter: number the partitions now
-        hipLaunchKernelGGL(k_dense_scan, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t*)so->cnt, n_seg * F, so->dense);
+        hipLaunchKernelGGL(k_dense_fix, dim3((unsigned)n_seg), dim3(1024), 0, ctx->stream, (const uint64_t*)seg_total, (uint32_t)F,
+                           so->dense);
         OLAP_HIP(ctx, hipGetLastError());
       }
       return OLAP_OK;
