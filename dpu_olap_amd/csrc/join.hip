@@ -1186,7 +1186,7 @@ static uint64_t seg_blocks(const olap_ctx* ctx, uint64_t n_seg) {
   uint64_t want = (uint64_t)ctx->compute_units * 4;
   uint64_t b = (want + n_seg - 1) / n_seg;
   if (b < 1) b = 1;
-  if (b > 256) b = 256;
+  if (b > 512) b = 512;  // two workgroups per CU when a single segment feeds the whole chip
   return b;
 }
 
