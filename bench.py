@@ -113,12 +113,21 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the hot path")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # Rehearsal on a one-GPU box (tests/test_bench_multirank_gpu.py): OLAP_BENCH_SHARE_GPU=1 puts every rank on
+    # cuda:0 and OLAP_BENCH_BACKEND=gloo carries the exchange (RCCL refuses two ranks on one device).  The
+    # driver's runs use neither: one rank per GPU over RCCL.
+    share_gpu = os.environ.get("OLAP_BENCH_SHARE_GPU") == "1"
+    backend = os.environ.get("OLAP_BENCH_BACKEND", "nccl")
+    dev_index = 0 if share_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
-    ctx = capi.Context(local_rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
+    ctx = capi.Context(dev_index)
     info = ctx.device_info()
     ops = GpuLocalOps(ctx, device)
     ctx.join_configure(args.radix_bits, args.max_bits_per_pass)
@@ -170,9 +179,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
+    host_wall = {}                 # N > 1: rank 0's wall time per stage of the exchange path (ms, summed over the timed steps)
+
     def step():
         ctx.set_profiling(True)    # Prepare(): per-phase HIP-event timers (inside the timed region, like the reference)
-        return distributed_join(ops, left, right)
+        return distributed_join(ops, left, right, timers=host_wall)
 
     result = None
     for _ in range(args.warmup):
@@ -180,6 +191,7 @@ def main():
         result = step()
     sync_all()
     ctx.reset_timers()
+    host_wall.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         result = None          # drop the previous step's output before allocating the next
@@ -244,6 +256,8 @@ def main():
             "config": {"workload": f"BM_Join u32 PK-FK SF={sf}: {sf} batches x 2Mi rows per side ({n_total} rows/side), "
                                    f"{world} x MI355X" + (", hash-owner split + all-to-all" if world > 1 else ""),
                        "sf": sf, "rows_per_side": n_total, "batch_rows": BATCH_ROWS, "radix": jinfo["stats"],
+                       "exchange": {"path": jinfo.get("path", "columns" if world > 1 else None), "backend": backend if world > 1 else None,
+                                    "sent_rows_rank0": jinfo.get("sent_rows", 0)},
                        "device": info["name"].strip()},
             "verified": verified, "rows_out": rows_out,
             "roofline": roofline,
@@ -252,6 +266,8 @@ def main():
                                     "note": "28 B per row-pair (SURVEY 8d) x rows/side / wall time per step, all GPUs"},
             "phase_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in timers.items()},
         }
+        if host_wall:
+            line["rank0_wall_ms_per_step"] = {k: round(v / args.steps, 3) for k, v in host_wall.items()}
         if world == 1 and not args.no_cpu_baseline:
             del left, right, result, ofk, oy, ox
             cb, arrow = cpu_baseline(os.cpu_count() or 1, args.cpu_sf)

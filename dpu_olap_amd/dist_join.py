@@ -23,6 +23,7 @@ gloo in tests (tests provide an oracle-backed ops object); the product backend i
 GpuLocalOps (C ABI on device pointers of torch CUDA tensors)."""
 from __future__ import annotations
 
+import time
 from typing import Sequence
 
 import torch
@@ -219,16 +220,24 @@ def distributed_join(ops, left_batches: Sequence, right_batches: Sequence, group
         # owner receives, per sender, its S sub-bucket runs, and its next pass reads them in
         # place.  The left table's exchange overlaps the split of the right table.
         S = (1 << FUSED_SPLIT_BITS) // world
+        t0 = time.perf_counter()
         pend_l, l_lo, l_hi, l_in, l_out = _fused_side(ops, lfk, ly, world, S, group, async_op=True)
+        t1 = time.perf_counter()   # left split + counts done, left tuples in flight
         pend_r, r_lo, r_hi, r_in, r_out = _fused_side(ops, rpk, rx, world, S, group, async_op=False)
         RR = pend_r.wait()
         RL = pend_l.wait()
         if RL.is_cuda:
             torch.cuda.current_stream(RL.device).synchronize()
+        t2 = time.perf_counter()   # right split + both exchanges done
         fk, y, x, stats = ops.join_presplit(RL, l_lo, l_hi, RR, r_lo, r_hi, S, world, g)
+        t3 = time.perf_counter()
         sent = sum(l_in) + sum(r_in) - l_in[rank] - r_in[rank]
+        wall = {"split_left+counts": (t1 - t0) * 1e3, "split_right+exchanges": (t2 - t1) * 1e3, "local_join": (t3 - t2) * 1e3}
+        if timers is not None:
+            for k, v in wall.items():
+                timers[k] = timers.get(k, 0.0) + v
         return fk, y, x, {"world": world, "stats": stats, "sent_rows": sent, "recv_left": sum(l_out),
-                          "recv_right": sum(r_out), "path": "fused"}
+                          "recv_right": sum(r_out), "path": "fused", "wall_ms": wall}
     if hasattr(ops, "partition_tuples"):
         # zipped path: one int64 tensor per table; the left table's exchange overlaps the
         # owner split of the right table (RCCL runs on its own stream)

@@ -1,0 +1,39 @@
+"""bench.py's multi-rank path end to end on the one GPU a gpurun box has: 2 and 4 ranks share
+cuda:0 (OLAP_BENCH_SHARE_GPU=1) and exchange over gloo (RCCL refuses two ranks on one device),
+launched exactly like the driver launches N > 1 (torch.distributed.run, one process per rank).
+Everything else is the product path: device generator, fused owner split
+(olap_partition_tuples_u32 with 512 buckets), counts + tuple exchange, olap_join_presplit_u32
+on the received chunks, digest verification across ranks."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,sf", [(2, 16), (4, 16)])
+def test_bench_multirank_on_one_gpu(world, sf):
+    env = dict(os.environ, OLAP_BENCH_SHARE_GPU="1", OLAP_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "1",
+           "--sf", str(sf), "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout          # rank 0 prints ONE json line
+    d = json.loads(lines[0])
+    assert d["verified"] and d["n_gpus"] == world and d["rows_out"] == sf * (2 << 20)
+    assert d["config"]["exchange"]["path"] == "fused" and d["scaling"] == "strong"
+    assert d["config"]["radix"]["missing_keys"] == 0
+    assert d["unit"] == "Mrows/s" and d["value"] > 0 and d["roofline"]["bound"] == "hbm"
