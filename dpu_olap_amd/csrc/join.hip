@@ -1617,6 +1617,10 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
   SideOut lso, rso;
   OLAP_TRY(partition_side(ctx, lcs, l_pay, in.l_tuples, NL, plan, (uint32_t)ctx->hash_skip_bits, tmp0, tmp1, Lt, lcap,
                           d_cnt + 4, &lso, in.l_pre, lclaim));
+  if (ctx->right_ready) {  // the right table may still be arriving (olap_join_set_right_ready_event)
+    OLAP_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->right_ready, 0));
+    ctx->right_ready = nullptr;
+  }
   OLAP_TRY(partition_side(ctx, rcs, r_pay, in.r_tuples, NR, plan, (uint32_t)ctx->hash_skip_bits, tmp0, tmp1, Rt, rcap,
                           d_cnt + 4, &rso, in.r_pre, rclaim));
   {
@@ -1763,6 +1767,12 @@ int olap_join_set_hash_skip_bits(olap_ctx* ctx, int bits) {
   if (!ctx) return OLAP_ERR_INVALID;
   if (bits < 0 || bits > 16) return ctx->fail(OLAP_ERR_INVALID, "hash skip bits must be in [0, 16]");
   ctx->hash_skip_bits = bits;
+  return OLAP_OK;
+}
+
+int olap_join_set_right_ready_event(olap_ctx* ctx, void* hip_event) {
+  if (!ctx) return OLAP_ERR_INVALID;
+  ctx->right_ready = static_cast<hipEvent_t>(hip_event);
   return OLAP_OK;
 }
 

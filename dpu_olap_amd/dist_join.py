@@ -40,6 +40,8 @@ class GpuLocalOps:
     """Local partition / join through libolap_gpu.so on torch CUDA tensors (int32 tensors
     carry the uint32 bit patterns; torch is only the allocator and the RCCL front end)."""
 
+    overlap_right_exchange = True   # fused path: the left table's radix pass runs under the right table's exchange
+
     def __init__(self, ctx: capi.Context, device: torch.device):
         self.ctx = ctx
         self.device = device
@@ -82,12 +84,17 @@ class GpuLocalOps:
         return out[0][:got], out[1][:got], out[2][:got], stats
 
     def join_presplit(self, lt: torch.Tensor, l_lo, l_hi, rt: torch.Tensor, r_lo, r_hi, n_segments: int, chunks: int,
-                      skip_bits: int = 0):
+                      skip_bits: int = 0, right_ready: "torch.cuda.Event | None" = None):
         """Local join of exchanged tuples that are still grouped (sender, sub-bucket): the first
-        radix pass reads the chunks in place (olap_join_presplit_u32)."""
+        radix pass reads the chunks in place (olap_join_presplit_u32).  right_ready: an event
+        recorded behind the right table's exchange -- the left table's pass then runs while the
+        right table is still arriving."""
         n = int(lt.numel())
         out = [self.empty(n) for _ in range(3)]
-        torch.cuda.current_stream(self.device).synchronize()  # inputs come from torch's stream; do not wait for RCCL's
+        if right_ready is None:
+            torch.cuda.current_stream(self.device).synchronize()  # inputs come from torch's stream; do not wait for RCCL's
+        else:
+            self.ctx.join_set_right_ready_event(right_ready.cuda_event)
         self.ctx.join_set_hash_skip_bits(skip_bits)
         try:
             got, stats = self.ctx.join_presplit_u32(lt.data_ptr(), n, l_lo, l_hi, rt.data_ptr(), int(rt.numel()), r_lo, r_hi,
@@ -223,13 +230,19 @@ def distributed_join(ops, left_batches: Sequence, right_batches: Sequence, group
         t0 = time.perf_counter()
         pend_l, l_lo, l_hi, l_in, l_out = _fused_side(ops, lfk, ly, world, S, group, async_op=True)
         t1 = time.perf_counter()   # left split + counts done, left tuples in flight
-        pend_r, r_lo, r_hi, r_in, r_out = _fused_side(ops, rpk, rx, world, S, group, async_op=False)
-        RR = pend_r.wait()
+        overlap = getattr(ops, "overlap_right_exchange", False)
+        pend_r, r_lo, r_hi, r_in, r_out = _fused_side(ops, rpk, rx, world, S, group, async_op=overlap)
         RL = pend_l.wait()
         if RL.is_cuda:
-            torch.cuda.current_stream(RL.device).synchronize()
-        t2 = time.perf_counter()   # right split + both exchanges done
-        fk, y, x, stats = ops.join_presplit(RL, l_lo, l_hi, RR, r_lo, r_hi, S, world, g)
+            torch.cuda.current_stream(RL.device).synchronize()   # the left table has arrived
+        ready = None
+        RR = pend_r.wait()          # RCCL: orders torch's stream behind the transfer, does not block the host
+        if overlap and RR.is_cuda:
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(RR.device))
+        t2 = time.perf_counter()   # right split done; exchanges done (or, overlapped, the right one still in flight)
+        fk, y, x, stats = (ops.join_presplit(RL, l_lo, l_hi, RR, r_lo, r_hi, S, world, g, right_ready=ready) if ready is not None
+                           else ops.join_presplit(RL, l_lo, l_hi, RR, r_lo, r_hi, S, world, g))
         t3 = time.perf_counter()
         sent = sum(l_in) + sum(r_in) - l_in[rank] - r_in[rank]
         wall = {"split_left+counts": (t1 - t0) * 1e3, "split_right+exchanges": (t2 - t1) * 1e3, "local_join": (t3 - t2) * 1e3}

@@ -223,6 +223,12 @@ int olap_join_presplit_u32(olap_ctx* ctx, const uint64_t* left_tuples, uint64_t 
                            uint32_t* out_y, uint32_t* out_x, uint64_t out_capacity, uint64_t* out_rows,
                            olap_join_stats* stats /* may be NULL */);
 
+/* One-shot: the NEXT join on this context partitions its left table first and makes the
+ * context's stream wait for `hip_event` (a recorded hipEvent_t) before it reads a byte of the
+ * right table -- so the right table's exchange can still be in flight when the join is
+ * called, and its transfer overlaps the left table's radix pass.  NULL clears it. */
+int olap_join_set_right_ready_event(olap_ctx* ctx, void* hip_event);
+
 /* Tuning knobs (0 = default).  radix_bits_total < 0 keeps the automatic choice
  * ceil(log2(right_rows / 4096)). */
 int olap_join_configure(olap_ctx* ctx, int radix_bits_total, int max_bits_per_pass);

@@ -617,7 +617,16 @@ def test_multirank_fused_split_loopback_on_one_gpu(dev, world):
             return (buf,) + _chunk_tables(cnt)
         RL, l_lo, l_hi = recv(0, 1)
         RR, r_lo, r_hi = recv(2, 3)
-        ofk, oy, ox, stats = ops.join_presplit(RL, l_lo, l_hi, RR, r_lo, r_hi, S, world, bits)
+        if r % 2:   # the overlapped form: the right table is "still arriving" (a copy in flight on torch's
+            # stream) when the join is called; the join's left pass runs meanwhile and its right pass waits for the event
+            torch.cuda.current_stream(device).synchronize()
+            RR2 = torch.empty_like(RR)
+            RR2.copy_(RR, non_blocking=True)
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(device))
+            ofk, oy, ox, stats = ops.join_presplit(RL, l_lo, l_hi, RR2, r_lo, r_hi, S, world, bits, right_ready=ready)
+        else:
+            ofk, oy, ox, stats = ops.join_presplit(RL, l_lo, l_hi, RR, r_lo, r_hi, S, world, bits)
         assert stats["missing_keys"] == 0 and stats["duplicate_keys"] == 0
         owner = oracle.wang_hash_np(ofk[:4096].cpu().numpy().view(np.uint32)) >> np.uint32(32 - bits)
         assert (owner == r).all()
