@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libolap_gpu.so")
-SOURCES = ["ctx.hip", "stage.hip", "scan_ops.hip", "join.hip", "gen.hip"]
+SOURCES = ["ctx.hip", "stage.hip", "scan_ops.hip", "join.hip", "gen.hip", "arrow_c.hip"]
 ARCH = "gfx950"
 
 
@@ -42,7 +42,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
     cc = hipcc()
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(ROOT, "include", "olap_gpu.h"), os.path.abspath(__file__)]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(ROOT, "include", "olap_gpu.h"), os.path.join(ROOT, "include", "olap_arrow.h"),
+               os.path.abspath(__file__)]
     jobs = []
     objs = []
     for s in SOURCES:

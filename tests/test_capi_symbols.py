@@ -33,6 +33,27 @@ def test_every_declared_symbol_is_exported(lib):
     assert lib.olap_abi_version() == 1
 
 
+def test_arrow_front_end_symbols_and_structs(lib):
+    """include/olap_arrow.h: every declared entry point is exported, and the ctypes mirror of the
+    Arrow C Data Interface structs has the ABI's size (80 / 72 bytes on LP64)."""
+    import ctypes as C
+    from dpu_olap_amd import arrow_cdata
+    hdr = open(os.path.join(ROOT, "include", "olap_arrow.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    syms = sorted(set(re.findall(r"\b(olap_arrow_[a-z0-9_]+)\s*\(", hdr)))
+    assert syms == sorted(arrow_cdata.EXPORTS) and len(syms) == 4
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/olap_arrow.h but not exported"
+    assert C.sizeof(arrow_cdata.ArrowArray) == 80 and C.sizeof(arrow_cdata.ArrowSchema) == 72
+    # round trip of the struct mirror through pyarrow (no GPU involved)
+    import pyarrow as pa
+    a = pa.array([1, 2, 3], type=pa.uint32()).slice(1)
+    ex = arrow_cdata._Exported([a])
+    assert ex.structs[0].length == 2 and ex.structs[0].offset == 1 and ex.structs[0].n_buffers == 2
+    ex.release()
+    assert not ex.structs[0].release
+
+
 def test_no_cpu_fallback_without_gpu():
     import torch
     if torch.cuda.is_available():

@@ -869,3 +869,44 @@ def test_join_claiming_first_pass(dev, shape):
     assert got == expect
     for c in cols.values():
         dev.release(o.DeviceArray(c.ptr, 0))
+
+
+# ------------------------------------------------ Arrow C Data Interface front end
+def test_arrow_c_data_interface_front_end(dev, golden):
+    """include/olap_arrow.h through pyarrow's C Data Interface export/import: sliced inputs
+    (non-zero offsets), results owned by pyarrow after the call, against pyarrow.compute."""
+    import pyarrow as pa
+    import pyarrow.compute as pc
+    from dpu_olap_amd import arrow_cdata as ac
+    rng = np.random.default_rng(3)
+    chunks = [pa.array(rng.integers(0, 1 << 32, size=n, dtype=np.uint32)) for n in (70000, 1, 0, 123457)]
+    chunks[0] = chunks[0].slice(5)                       # offset 5
+    col = pa.chunked_array(chunks)
+    out, total = ac.filter_lt(dev, col, 1 << 30)
+    assert out.num_chunks == col.num_chunks and total == len(out)
+    for a, b in zip(out.chunks, col.chunks):
+        assert a.equals(pc.filter(b, pc.less(b, pa.scalar(1 << 30, pa.uint32()))))
+    assert ac.sum_(dev, col) == pc.sum(col).as_py()
+    i64 = pa.chunked_array([pa.array(rng.integers(-(1 << 40), 1 << 40, size=5000, dtype=np.int64)) for _ in range(3)])
+    out64, _ = ac.filter_lt(dev, i64, 0)
+    assert out64.equals(pc.filter(i64, pc.less(i64, 0))) and ac.sum_(dev, i64) == pc.sum(i64).as_py()
+    data = [c for c in col.chunks if len(c)]
+    idx = [pa.array(rng.integers(0, len(c), size=1000, dtype=np.uint32)) for c in data]
+    for got, d, i in zip(ac.take(dev, data, idx), data, idx):
+        assert got.equals(d.take(i))
+    # join: golden case b in its ragged batches, plus the selection-vector form
+    fk, y, pk, x = (golden[f"join_b_{k}"] for k in ("fk", "y", "pk", "x"))
+    cut = lambda a, sizes: pa.chunked_array([pa.array(c) for c in split_batches(a, sizes)])
+    lrows, rrows = golden["join_b_left_rows"], golden["join_b_right_rows"]
+    tbl, stats = ac.join(dev, cut(fk, lrows), cut(y, lrows), cut(pk, rrows), cut(x, rrows))
+    assert stats["missing_keys"] == 0 and tbl.num_rows == fk.size
+    a, b_, c = sort_rows(*(tbl[k].to_numpy() for k in ("fk", "y", "x")))
+    np.testing.assert_array_equal(a, golden["join_b_out_fk"])
+    np.testing.assert_array_equal(b_, golden["join_b_out_y"])
+    np.testing.assert_array_equal(c, golden["join_b_out_x"])
+    sel, _ = ac.join(dev, cut(fk, lrows), None, cut(pk, rrows), None)
+    np.testing.assert_array_equal(pk[sel["x"].to_numpy()], sel["fk"].to_numpy())
+    np.testing.assert_array_equal(fk[sel["y"].to_numpy()], sel["fk"].to_numpy())
+    del tbl, sel, out, out64                              # release callbacks run here
+    with pytest.raises(ac.capi.OlapError):               # nulls are refused, not silently read
+        ac.sum_(dev, pa.chunked_array([pa.array([1, None, 3], type=pa.uint32())]))
