@@ -86,6 +86,7 @@ struct olap_ctx {
   int capacity_mode = 1;   // last radix pass without histogram (fixed-capacity regions + exact fallback)
   int claim_mode = 1;      // pass 0 of a two-pass plan without histogram (claimed allotments): 0 off, 1 auto, 2 always
   int hash_skip_bits = 0;  // top hash bits already fixed by an upstream owner split
+  int join_drop_unmatched = 0;       // 1: inner-join semantics (rows without a match are dropped, not an error)
   hipEvent_t right_ready = nullptr;  // one-shot: the next join waits for it before reading its right table
 
   // OLAP_MEM_HOST operands

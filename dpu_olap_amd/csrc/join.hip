@@ -866,7 +866,7 @@ struct PartView {
 __global__ __launch_bounds__(kJBlock, 4) void k_join_probe(PartView RV, PartView LV, uint32_t nparts,
                                                            uint32_t* out_fk, uint32_t* out_y,
                                                            uint32_t* out_x, uint32_t pair_store_ok,
-                                                           unsigned long long* counters) {
+                                                           unsigned long long* counters, uint32_t* miss_bits) {
   const uint2* R = RV.t;
   const uint2* L = LV.t;
   __shared__ uint32_t s_keys[kSlots];
@@ -972,7 +972,10 @@ __global__ __launch_bounds__(kJBlock, 4) void k_join_probe(PartView RV, PartView
                 slot = (slot + 1) & (kSlots - 1);
               }
             }
-            if (!hit) ++my_miss;
+            if (!hit) {
+              ++my_miss;
+              if (miss_bits) atomicOr(&miss_bits[(i0 + h + delta) >> 5], 1u << ((i0 + h + delta) & 31));  // drop mode: mark the row
+            }
           }
           if (ok[0] && ok[1] && pair_store) {  // i0 is even: 8-byte aligned pair stores
             const uint64_t o = i0 + delta;
@@ -1026,7 +1029,8 @@ constexpr int kDBlock = 512;
 __global__ __launch_bounds__(kDBlock, 4) void k_join_probe_direct(PartView RV, PartView LV, uint32_t nparts,
                                                                uint32_t table_bits, uint32_t* out_fk,
                                                                uint32_t* out_y, uint32_t* out_x,
-                                                               uint32_t pair_store_ok, unsigned long long* counters) {
+                                                               uint32_t pair_store_ok, unsigned long long* counters,
+                                                               uint32_t* miss_bits) {
   __shared__ uint32_t s_vals[kDSlots];
   __shared__ uint32_t s_used[kDSlots / 32];
   const uint2* R = RV.t;
@@ -1109,7 +1113,10 @@ __global__ __launch_bounds__(kDBlock, 4) void k_join_probe_direct(PartView RV, P
             const uint32_t slot = wang_hash(k) & smask;
             const bool hit = (s_used[slot >> 5] >> (slot & 31)) & 1u;
             xs[h] = s_vals[slot];
-            if (!hit) ++my_miss;
+            if (!hit) {
+              ++my_miss;
+              if (miss_bits) atomicOr(&miss_bits[(i0 + h + delta) >> 5], 1u << ((i0 + h + delta) & 31));  // drop mode: mark the row
+            }
           }
           const uint64_t o = i0 + delta;
           if (ok[0] && ok[1] && pair_store) {
@@ -1156,6 +1163,51 @@ struct PassPlan {
   uint32_t bits[kMaxPasses] = {0, 0, 0, 0};
   uint32_t total_bits = 0;
 };
+
+// ---- inner-join mode: rows whose foreign key found no primary key are dropped
+constexpr uint32_t kCompactSeg = 1u << 16;  // rows per compaction segment (2048 bitmap words)
+
+// kept[s] = rows of segment s that are not marked in the miss bitmap
+__global__ __launch_bounds__(256) void k_compact_count(const uint32_t* miss_bits, uint64_t n_rows, uint32_t* kept) {
+  __shared__ uint32_t s_wave[4];
+  const uint64_t seg = blockIdx.x;
+  const uint64_t lo = seg * kCompactSeg, hi = min(n_rows, lo + kCompactSeg);
+  uint32_t marked = 0;
+  for (uint64_t w = lo / 32 + threadIdx.x; w * 32 < hi; w += 256) {
+    uint32_t bits = miss_bits[w];
+    if (hi - w * 32 < 32) bits &= (1u << (hi - w * 32)) - 1u;
+    marked += __popc(bits);
+  }
+  marked = (uint32_t)wave_reduce_add((uint64_t)marked);
+  if (lane_id() == 0) s_wave[threadIdx.x / kWave] = marked;
+  __syncthreads();
+  if (threadIdx.x == 0) kept[seg] = (uint32_t)(hi - lo) - (s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3]);
+}
+
+// dst[base[s] + rank] = src[row] for the unmarked rows of segment s, order preserved
+__global__ __launch_bounds__(256) void k_compact_rows(const uint32_t* src, const uint32_t* miss_bits, const uint64_t* base,
+                                                      uint64_t n_rows, uint32_t* dst) {
+  __shared__ uint32_t s_wave[4];
+  __shared__ uint32_t s_run;
+  const uint64_t seg = blockIdx.x;
+  const uint64_t lo = seg * kCompactSeg, hi = min(n_rows, lo + kCompactSeg);
+  if (threadIdx.x == 0) s_run = 0;
+  __syncthreads();
+  for (uint64_t r0 = lo; r0 < hi; r0 += 256) {
+    const uint64_t row = r0 + threadIdx.x;
+    const bool keep = row < hi && !((miss_bits[row >> 5] >> (row & 31)) & 1u);
+    const unsigned long long ballot = __ballot(keep);
+    const uint32_t before = __popcll(ballot & ((1ull << lane_id()) - 1ull));
+    if (lane_id() == 0) s_wave[threadIdx.x / kWave] = (uint32_t)__popcll(ballot);
+    __syncthreads();
+    uint32_t off = s_run;
+    for (unsigned w = 0; w < threadIdx.x / kWave; ++w) off += s_wave[w];
+    if (keep) dst[base[seg] + off + before] = src[row];
+    __syncthreads();
+    if (threadIdx.x == 0) s_run += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    __syncthreads();
+  }
+}
 
 static int ceil_log2_u64(uint64_t x) {
   int l = 0;
@@ -1553,7 +1605,7 @@ struct JoinIn {
 
 static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t* out_y, uint32_t* out_x, int out_mem,
                      uint64_t NL, uint64_t NR, uint32_t total_bits, bool allow_capacity, olap_join_stats* st,
-                     unsigned long long counters[5]) {
+                     unsigned long long counters[5], uint64_t* rows_out) {
   const uint32_t* const* lfk = in.lfk;
   const uint32_t* const* ly = in.ly;
   const uint32_t* const* rpk = in.rpk;
@@ -1593,6 +1645,9 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
   if (plan.passes >= 2) need += align_up((tmp_tuples + 2) * 8, 256);
   if (plan.passes >= 3) need += align_up((maxN + 2) * 8, 256);
   if (out_mem == OLAP_MEM_HOST) need += 3 * align_up(NL * 4 + 4, 256);
+  const bool drop = ctx->join_drop_unmatched != 0;
+  const uint64_t miss_words = (NL + 31) / 32 + 2;
+  if (drop) need += align_up(miss_words * 4, 256);
   uint64_t pin = (lnb + rnb + 2) * 8 * 8 + 8192;
   if (in.l_pre) pin += 2 * ((uint64_t)in.l_pre->n_seg * in.l_pre->chunks * 16 + ((uint64_t)in.l_pre->n_seg + 1) * 8 + 512);
   OLAP_TRY(pinned_begin(ctx, pin));
@@ -1614,6 +1669,12 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
   if ((plan.passes >= 2 && !tmp0) || (plan.passes >= 3 && !tmp1) || !Lt || !Rt || !d_cnt || !d_fk || !d_y || !d_x)
     return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (join buffers)");
   OLAP_HIP(ctx, hipMemsetAsync(d_cnt, 0, 40, ctx->stream));
+  uint32_t* miss_bits = nullptr;  // inner-join mode: one bit per output row, set where the probe missed
+  if (drop) {
+    miss_bits = (uint32_t*)ws_alloc(ctx, miss_words * 4);
+    if (!miss_bits) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (miss bitmap)");
+    OLAP_HIP(ctx, hipMemsetAsync(miss_bits, 0, miss_words * 4, ctx->stream));
+  }
   SideOut lso, rso;
   OLAP_TRY(partition_side(ctx, lcs, l_pay, in.l_tuples, NL, plan, (uint32_t)ctx->hash_skip_bits, tmp0, tmp1, Lt, lcap,
                           d_cnt + 4, &lso, in.l_pre, lclaim));
@@ -1634,18 +1695,72 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
       uint64_t dgrid = (uint64_t)ctx->compute_units * 8;
       if (dgrid > P) dgrid = P;
       hipLaunchKernelGGL(k_join_probe_direct, dim3((unsigned)dgrid), dim3(kDBlock), 0, ctx->stream, rv, lv, P, table_bits,
-                         d_fk, d_y, d_x, pair_ok, d_cnt);
+                         d_fk, d_y, d_x, pair_ok, d_cnt, miss_bits);
     } else {
       hipLaunchKernelGGL(k_join_probe, dim3((unsigned)grid), dim3(kJBlock), 0, ctx->stream, rv, lv, P, d_fk, d_y, d_x,
-                         pair_ok, d_cnt);
+                         pair_ok, d_cnt, miss_bits);
     }
     OLAP_HIP(ctx, hipGetLastError());
   }
   OLAP_HIP(ctx, hipMemcpyAsync(counters, d_cnt, 40, hipMemcpyDeviceToHost, ctx->stream));
   OLAP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if (out_mem == OLAP_MEM_HOST && counters[2] == 0 && counters[0] == 0 && counters[4] == 0 && NL) {
+  const bool sound = counters[2] == 0 && counters[4] == 0;  // no table / region overflow: the rows written are final
+  uint64_t kept_rows = NL;
+  if (drop && sound && counters[0]) {
+    // inner join: squeeze the marked rows out of the three columns, order preserved
+    const uint64_t n_seg = (NL + kCompactSeg - 1) / kCompactSeg;
+    uint32_t* d_kept = nullptr;
+    uint64_t* d_base = nullptr;
+    uint32_t* d_tmp = nullptr;
+    std::vector<uint32_t> kept(n_seg);
+    std::vector<uint64_t> base(n_seg + 1, 0);
+    int rc = OLAP_OK;
+    do {
+      if (hipMalloc(&d_kept, n_seg * 4) != hipSuccess || hipMalloc(&d_base, n_seg * 8) != hipSuccess) {
+        rc = ctx->fail(OLAP_ERR_NOMEM, "device allocation for the row compaction failed");
+        break;
+      }
+      hipLaunchKernelGGL(k_compact_count, dim3((unsigned)n_seg), dim3(256), 0, ctx->stream, (const uint32_t*)miss_bits, NL, d_kept);
+      if (hipMemcpyAsync(kept.data(), d_kept, n_seg * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+          hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        rc = ctx->fail(OLAP_ERR_DEVICE, "row compaction (count) failed");
+        break;
+      }
+      for (uint64_t k = 0; k < n_seg; ++k) base[k + 1] = base[k] + kept[k];
+      kept_rows = base[n_seg];
+      if (kept_rows + counters[0] != NL) {
+        rc = ctx->fail(OLAP_ERR_DEVICE, "internal: miss bitmap (%llu rows kept) disagrees with the miss counter (%llu of %llu)",
+                       (unsigned long long)kept_rows, counters[0], (unsigned long long)NL);
+        break;
+      }
+      if (hipMalloc(&d_tmp, kept_rows * 4 + 4) != hipSuccess) {
+        rc = ctx->fail(OLAP_ERR_NOMEM, "device allocation of %llu bytes for the row compaction failed", (unsigned long long)(kept_rows * 4));
+        break;
+      }
+      if (hipMemcpyAsync(d_base, base.data(), n_seg * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+        rc = ctx->fail(OLAP_ERR_DEVICE, "row compaction (bases) failed");
+        break;
+      }
+      for (uint32_t* col : {d_fk, d_y, d_x}) {
+        hipLaunchKernelGGL(k_compact_rows, dim3((unsigned)n_seg), dim3(256), 0, ctx->stream, (const uint32_t*)col,
+                           (const uint32_t*)miss_bits, (const uint64_t*)d_base, NL, d_tmp);
+        if (hipMemcpyAsync(col, d_tmp, kept_rows * 4, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) {
+          rc = ctx->fail(OLAP_ERR_DEVICE, "row compaction (copy back) failed");
+          break;
+        }
+      }
+      if (rc == OLAP_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = ctx->fail(OLAP_ERR_DEVICE, "row compaction failed");
+    } while (false);
+    (void)hipFree(d_kept);
+    (void)hipFree(d_base);
+    (void)hipFree(d_tmp);
+    if (rc != OLAP_OK) return rc;
+  }
+  if (rows_out) *rows_out = kept_rows;
+  if (out_mem == OLAP_MEM_HOST && sound && (counters[0] == 0 || drop) && kept_rows) {
     PhaseScope ps(ctx, PH_COPY_FROM);
-    OLAP_TRY(stage_d2h(ctx, {StageItem{d_fk, out_fk, NL * 4}, StageItem{d_y, out_y, NL * 4}, StageItem{d_x, out_x, NL * 4}}));
+    OLAP_TRY(stage_d2h(ctx, {StageItem{d_fk, out_fk, kept_rows * 4}, StageItem{d_y, out_y, kept_rows * 4},
+                             StageItem{d_x, out_x, kept_rows * 4}}));
     OLAP_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
   if (st) {
@@ -1672,6 +1787,7 @@ static int join_run(olap_ctx* ctx, const JoinIn& jin, uint64_t NL, uint64_t NR, 
   if (!out_fk || !out_y || !out_x) return ctx->fail(OLAP_ERR_INVALID, "null output column");
   if (NR == 0) {
     if (stats) { stats->left_rows = NL; stats->missing_keys = NL; }
+    if (ctx->join_drop_unmatched) return OLAP_OK;  // inner join with an empty build side: no rows
     return ctx->fail(OLAP_ERR_NO_MATCH, "right table is empty: %llu foreign keys without a match", (unsigned long long)NL);
   }
   uint32_t bits;
@@ -1687,9 +1803,10 @@ static int join_run(olap_ctx* ctx, const JoinIn& jin, uint64_t NL, uint64_t NR, 
   }
   if (jin.l_pre && bits <= jin.l_pre->bits) bits = jin.l_pre->bits + 1;  // at least one pass gathers the chunks
   unsigned long long counters[5] = {0, 0, 0, 0, 0};
+  uint64_t kept_rows = NL;
   bool allow_capacity = true;
   for (int attempt = 0; attempt < 4; ++attempt) {
-    OLAP_TRY(join_once(ctx, jin, out_fk, out_y, out_x, out_mem, NL, NR, bits, allow_capacity, stats, counters));
+    OLAP_TRY(join_once(ctx, jin, out_fk, out_y, out_x, out_mem, NL, NR, bits, allow_capacity, stats, counters, &kept_rows));
     if (counters[4]) {  // a fixed-capacity region overflowed (skew): redo with exact partitioning
       allow_capacity = false;
       continue;
@@ -1701,9 +1818,9 @@ static int join_run(olap_ctx* ctx, const JoinIn& jin, uint64_t NL, uint64_t NR, 
   if (counters[2])
     return ctx->fail(OLAP_ERR_OVERFLOW, "%llu partition(s) exceed the LDS hash table (%u rows); largest build partition %llu rows",
                      counters[2], kTableCap, counters[3]);
-  if (counters[0])
+  if (counters[0] && !ctx->join_drop_unmatched)
     return ctx->fail(OLAP_ERR_NO_MATCH, "%llu foreign key(s) without a matching primary key", counters[0]);
-  *out_rows = NL;
+  *out_rows = kept_rows;
   return OLAP_OK;
 }
 
@@ -1773,6 +1890,13 @@ int olap_join_set_hash_skip_bits(olap_ctx* ctx, int bits) {
 int olap_join_set_right_ready_event(olap_ctx* ctx, void* hip_event) {
   if (!ctx) return OLAP_ERR_INVALID;
   ctx->right_ready = static_cast<hipEvent_t>(hip_event);
+  return OLAP_OK;
+}
+
+int olap_join_set_unmatched(olap_ctx* ctx, int mode) {
+  if (!ctx) return OLAP_ERR_INVALID;
+  if (mode != OLAP_UNMATCHED_ERROR && mode != OLAP_UNMATCHED_DROP) return ctx->fail(OLAP_ERR_INVALID, "unknown unmatched-row mode %d", mode);
+  ctx->join_drop_unmatched = mode == OLAP_UNMATCHED_DROP;
   return OLAP_OK;
 }
 

@@ -227,6 +227,31 @@ TEST(JoinTest, WideTablesGoThroughSelectionVectors) {
   for (const auto& name : n64->schema()->field_names()) EXPECT_TRUE(n64->GetColumnByName(name)->Equals(g64->GetColumnByName(name)));
 }
 
+TEST(JoinTest, InnerJoinDropsUnmatchedLikeNative) {
+  // half of the foreign keys have no primary key: JoinNative (Arrow inner hash join) drops those rows,
+  // and so does JoinGpu when asked to
+  arrow::random::RandomArrayGenerator rng(8);
+  const int num_batches = 8, batch_size = 40000;
+  auto dev = Gpu();
+  auto right = AddColumn("pk", MakeRandomRecordBatches(rng, OneColumn("x"), num_batches, batch_size),
+                         MakeIndexColumn(num_batches, batch_size).ValueOrDie());
+  // foreign keys drawn from twice the key range of the matching batch pair
+  auto left = AddColumn("fk", MakeRandomRecordBatches(rng, OneColumn("y"), num_batches, batch_size),
+                        MakeForeignKeyColumn(rng, 2 * batch_size, num_batches, batch_size).ValueOrDie());
+  auto native = SortedBy(Go(join::JoinNative{left[0]->schema(), right[0]->schema(), left, right}).ValueOrDie(), {"fk", "y"});
+  join::JoinGpu strict{*dev, left[0]->schema(), right[0]->schema(), left, right};
+  EXPECT_FALSE(Go(strict).ok());
+  join::JoinGpu inner{*dev, left[0]->schema(), right[0]->schema(), left, right};
+  inner.DropUnmatched(true);
+  auto gpu = SortedBy(Go(inner).ValueOrDie(), {"fk", "y"});
+  EXPECT_GT(native->num_rows(), 0);
+  EXPECT_LT(native->num_rows(), (int64_t)num_batches * batch_size);
+  EXPECT_EQ(gpu->num_rows(), native->num_rows());
+  EXPECT_EQ((int64_t)inner.Stats().missing_keys, (int64_t)num_batches * batch_size - native->num_rows());
+  for (const auto& name : native->schema()->field_names())
+    EXPECT_TRUE(native->GetColumnByName(name)->Equals(gpu->GetColumnByName(name)));
+}
+
 TEST(JoinTest, MissingForeignKeyIsAnError) {
   auto left = RecordBatchOf({"fk", "y"}, {ArrayOf<U32>({1, 77}), ArrayOf<U32>({5, 6})});
   auto right = RecordBatchOf({"pk", "x"}, {ArrayOf<U32>({1, 2, 3}), ArrayOf<U32>({7, 8, 9})});

@@ -193,6 +193,11 @@ arrow::Result<std::shared_ptr<arrow::Table>> JoinGpu::Run() {
     if (c != pk) fields.push_back(right_schema_->field(c));
   std::vector<std::shared_ptr<arrow::Array>> columns;
   uint64_t out_rows = 0;
+  ARROW_RETURN_NOT_OK(system_.Check(olap_join_set_unmatched(system_.ctx(), drop_unmatched_ ? OLAP_UNMATCHED_DROP : OLAP_UNMATCHED_ERROR)));
+  struct Restore {
+    olap_ctx* ctx;
+    ~Restore() { (void)olap_join_set_unmatched(ctx, OLAP_UNMATCHED_ERROR); }
+  } restore{system_.ctx()};
   ARROW_ASSIGN_OR_RAISE(auto out, olap::AllocateOutputs({n_left, n_left, n_left}, 4));
   auto* o0 = static_cast<uint32_t*>(out.ptrs[0]);
   auto* o1 = static_cast<uint32_t*>(out.ptrs[1]);

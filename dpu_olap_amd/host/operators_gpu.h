@@ -97,6 +97,12 @@ class JoinGpu : public GpuOperator {
         left_batches_(std::move(left_batches)), right_batches_(std::move(right_batches)) {}
   arrow::Result<std::shared_ptr<arrow::Table>> Run();
   const olap_join_stats& Stats() const { return stats_; }
+  // true: inner-join semantics like JoinNative's Arrow hash join (left rows without a match are dropped);
+  // false (default): they are an error, as in the reference's DPU path (hash_probe.c:33-34)
+  JoinGpu& DropUnmatched(bool drop) {
+    drop_unmatched_ = drop;
+    return *this;
+  }
 
  private:
   arrow::Result<std::shared_ptr<arrow::Array>> Gather(const arrow::RecordBatchVector& batches, int column,
@@ -107,6 +113,7 @@ class JoinGpu : public GpuOperator {
   std::shared_ptr<arrow::Schema> left_schema_, right_schema_;
   arrow::RecordBatchVector left_batches_, right_batches_;
   olap_join_stats stats_{};
+  bool drop_unmatched_ = false;
 };
 }  // namespace join
 

@@ -269,12 +269,14 @@ class JoinGpu(_Op):
     join_dpu.cc:314-363), partition-major row order (sort before comparing, as
     host/join/join_test.cc:27-38 does).  A batch is a (key, payload) pair."""
 
-    def __init__(self, system: Device, left_batches: Sequence, right_batches: Sequence, select: bool = False):
+    def __init__(self, system: Device, left_batches: Sequence, right_batches: Sequence, select: bool = False,
+                 drop_unmatched: bool = False):
         """select=True: batches are bare key columns and the result's "y" / "x" are selection
         vectors -- the global left row index of every result row and the global right row index
         of its match (what kernel_hash_probe returns; gather further columns with TakeGpu)."""
         super().__init__(system)
         self.select = select
+        self.drop_unmatched = drop_unmatched   # inner join: left rows without a match are dropped instead of raising
         if select:
             self.lfk, self.ly, self.rpk, self.rx = list(left_batches), None, list(right_batches), None
         else:
@@ -288,6 +290,13 @@ class JoinGpu(_Op):
 
     def Run(self) -> dict:
         self._need_prepare()
+        self.system_.join_set_unmatched(self.drop_unmatched)
+        try:
+            return self._run()
+        finally:
+            self.system_.join_set_unmatched(False)
+
+    def _run(self) -> dict:
         lfk, rpk = self._u32(self.lfk), self._u32(self.rpk)
         ly, rx = ([], []) if self.select else (self._u32(self.ly), self._u32(self.rx))
         lp, lrows, lmem, _ = _table(lfk)

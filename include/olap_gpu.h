@@ -223,6 +223,14 @@ int olap_join_presplit_u32(olap_ctx* ctx, const uint64_t* left_tuples, uint64_t 
                            uint32_t* out_y, uint32_t* out_x, uint64_t out_capacity, uint64_t* out_rows,
                            olap_join_stats* stats /* may be NULL */);
 
+/* What a foreign key without a matching primary key does.  OLAP_UNMATCHED_ERROR (default):
+ * the join fails with OLAP_ERR_NO_MATCH -- the reference asserts on it
+ * (dpu/shared/kernels/hash_probe.c:33-34).  OLAP_UNMATCHED_DROP: inner-join semantics, like
+ * the Arrow hash join behind JoinNative (host/join/join_native.cc:31-49): such rows are left
+ * out, *out_rows < left rows, stats->missing_keys says how many. */
+enum { OLAP_UNMATCHED_ERROR = 0, OLAP_UNMATCHED_DROP = 1 };
+int olap_join_set_unmatched(olap_ctx* ctx, int mode);
+
 /* One-shot: the NEXT join on this context partitions its left table first and makes the
  * context's stream wait for `hip_event` (a recorded hipEvent_t) before it reads a byte of the
  * right table -- so the right table's exchange can still be in flight when the join is

@@ -910,3 +910,41 @@ def test_arrow_c_data_interface_front_end(dev, golden):
     del tbl, sel, out, out64                              # release callbacks run here
     with pytest.raises(ac.capi.OlapError):               # nulls are refused, not silently read
         ac.sum_(dev, pa.chunked_array([pa.array([1, None, 3], type=pa.uint32())]))
+
+
+@pytest.mark.parametrize("space", ["host", "device"])
+@pytest.mark.parametrize("size", ["small", "large"])
+def test_join_drop_unmatched_is_an_inner_join(dev, space, size):
+    """OLAP_UNMATCHED_DROP: rows whose foreign key has no primary key are left out (Arrow's
+    inner hash join, the reference's JoinNative); default mode stays an error.  small: probing
+    table; large: direct-address table + capacity layout; misses spread over all partitions."""
+    o = _ops()
+    rng = np.random.default_rng(9)
+    nr, nl, nb = (20_000, 50_000, 3) if size == "small" else (40_000_000, 30_000_000, 6)
+    pk = (rng.permutation(nr).astype(np.uint32) * np.uint32(2))            # even keys only
+    x = rng.integers(0, 1 << 32, size=nr, dtype=np.uint32)
+    fk = rng.integers(0, 2 * nr, size=nl, dtype=np.uint32)                  # about half of them odd -> no match
+    fk[:5] = (2 * nr + 7, 0xFFFFFFFF, 1, 3, 5)
+    y = np.arange(nl, dtype=np.uint32)
+    cut = lambda a: np.array_split(a, nb)
+    wrap = (lambda a: a) if space == "host" else dev.to_device
+    left = [(wrap(k), wrap(p)) for k, p in zip(cut(fk), cut(y))]
+    right = [(wrap(k), wrap(p)) for k, p in zip(cut(pk), cut(x))]
+    with pytest.raises(o.OlapError):
+        o.JoinGpu(dev, left, right).Prepare().Run()
+    j = o.JoinGpu(dev, left, right, drop_unmatched=True).Prepare()
+    r = j.Run()
+    get = (lambda a: a) if space == "host" else dev.to_host
+    ofk, oy, ox = get(r["fk"]), get(r["y"]), get(r["x"])
+    keep = (fk % 2 == 0) & (fk < 2 * nr)
+    assert j.stats["missing_keys"] == int((~keep).sum()) and ofk.size == int(keep.sum())
+    lut = np.zeros(2 * nr, np.uint32)
+    lut[pk] = x
+    np.testing.assert_array_equal(np.sort(oy), y[keep])                     # exactly the matching left rows, once each
+    np.testing.assert_array_equal(fk[oy], ofk)
+    np.testing.assert_array_equal(lut[ofk], ox)
+    # still fine when nothing is missing, and with an empty build side
+    r2 = o.JoinGpu(dev, [(wrap(pk[:1000].copy()), wrap(x[:1000].copy()))], right, drop_unmatched=True).Prepare().Run()
+    assert get(r2["fk"]).size == 1000
+    r3 = o.JoinGpu(dev, left[:1], [], drop_unmatched=True).Prepare().Run()
+    assert get(r3["fk"]).size == 0
