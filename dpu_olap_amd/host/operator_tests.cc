@@ -227,7 +227,7 @@ TEST(JoinTest, WideTablesGoThroughSelectionVectors) {
   for (const auto& name : n64->schema()->field_names()) EXPECT_TRUE(n64->GetColumnByName(name)->Equals(g64->GetColumnByName(name)));
 }
 
-TEST(JoinTest, InnerJoinDropsUnmatchedLikeNative) {
+TEST(JoinTest, InnerJoinDropsUnmatched) {
   // half of the foreign keys have no primary key: JoinNative (Arrow inner hash join) drops those rows,
   // and so does JoinGpu when asked to
   arrow::random::RandomArrayGenerator rng(8);
