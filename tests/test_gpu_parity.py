@@ -948,3 +948,62 @@ def test_join_drop_unmatched_is_an_inner_join(dev, space, size):
     assert get(r2["fk"]).size == 1000
     r3 = o.JoinGpu(dev, left[:1], [], drop_unmatched=True).Prepare().Run()
     assert get(r3["fk"]).size == 0
+
+
+# ----------------------------------------------------------- randomized shapes
+@pytest.mark.parametrize("seed", range(48))
+def test_join_random_shapes_and_plans_vs_oracle(dev, seed):
+    """Seeded random join shapes (empty / one-row / ragged batches, full-range keys incl.
+    0xFFFFFFFF and 0) under random radix plans and kernel variants (tile-staged or
+    write-combining scatter, exact / capacity / claiming layouts, probing or direct table,
+    both workgroup geometries, 64- or 128-byte lines), host or device operands -- rows must
+    equal the CPU oracle's join as a sorted set."""
+    o = _ops()
+    rng = np.random.default_rng(1000 + seed)
+    big = seed % 6 == 0
+    def sizes(k):
+        s = [int(x) for x in rng.choice([0, 1, 2, 7, 4095, 4096, 4097, 9000, 20011], size=k)]
+        if big and s:
+            s[int(rng.integers(len(s)))] = int(rng.integers(200_000, 600_000))
+        return s
+    rrows, lrows = sizes(int(rng.integers(1, 6))), sizes(int(rng.integers(0, 6)))
+    nr = sum(rrows)
+    if nr == 0:
+        rrows[0] = nr = 5
+    pk = rng.choice(1 << 32, size=nr, replace=False).astype(np.uint32) if not big else (rng.permutation(nr).astype(np.uint32) + np.uint32(1)) * np.uint32(4099)
+    if seed % 3 == 0:
+        pk[0] = 0xFFFFFFFF
+    if seed % 4 == 0 and nr > 1:
+        pk[1] = 0
+    x = rng.integers(0, 1 << 32, size=nr, dtype=np.uint32)
+    fk = pk[rng.integers(0, nr, size=sum(lrows))]
+    y = rng.integers(0, 1 << 32, size=fk.size, dtype=np.uint32)
+    space = "device" if seed % 2 else "host"
+    wrap = (lambda a: a) if space == "host" else dev.to_device
+    left = [(wrap(k), wrap(p)) for k, p in zip(split_batches(fk, lrows), split_batches(y, lrows))]
+    right = [(wrap(k), wrap(p)) for k, p in zip(split_batches(pk, rrows), split_batches(x, rrows))]
+    bits = int(rng.choice([-1, -1, 1, 3, 6, 9, 11, 14]))
+    if bits >= 0 and nr >> bits > 6000:
+        bits = -1                               # keep build partitions inside the probing table
+    knobs = {"scatter_variant": int(rng.integers(2)), "capacity_mode": int(rng.integers(2)), "claim_mode": int(rng.choice([0, 2])),
+             "direct_table": int(rng.integers(2)), "wc_geometry": int(rng.choice([1, 2])), "line16": int(rng.integers(2))}
+    per_pass = int(rng.choice([0, 0, 3, 5, 8, 10]))
+    if per_pass and max(bits, 8) > 4 * per_pass:
+        per_pass = 0                            # more than 4 passes is a configuration error
+    dev.join_configure(bits, per_pass)
+    for k, v in knobs.items():
+        dev.set_tuning(k, v)
+    try:
+        j = o.JoinGpu(dev, left, right).Prepare()
+        r = j.Run()
+    finally:
+        dev.join_configure(-1, 0)
+        for k, v in {"scatter_variant": 0, "capacity_mode": 1, "claim_mode": 1, "direct_table": 1, "wc_geometry": 2, "line16": 0}.items():
+            dev.set_tuning(k, v)
+    get = (lambda a: a) if space == "host" else dev.to_host
+    got = sort_rows(get(r["fk"]), get(r["y"]), get(r["x"]))
+    exp = sort_rows(*oracle.join(split_batches(fk, lrows), split_batches(y, lrows), split_batches(pk, rrows), split_batches(x, rrows),
+                                 nr_partitions=4))
+    assert got[0].size == fk.size, (knobs, bits, j.stats)
+    for g, e in zip(got, exp):
+        np.testing.assert_array_equal(g, e, err_msg=f"{knobs} bits={bits} stats={j.stats}")
