@@ -1,1161 +1,24 @@
-// join.hip -- radix partition and radix-partitioned PK-FK hash join for gfx950.
+// join.hip -- host side of the radix partition and the radix-partitioned PK-FK hash join
+// (olap_partition_*, olap_join_*): plans the passes, sizes the arena, launches the kernels of
+// radix_kernels.h / probe_kernels.h, handles the retries.
 //
-// Reference behaviour (upmem/dpu_olap):
-//   partition  dpu/shared/kernels/partition.c:20-28 (wang hash), :45-46 (bucket =
-//              top bits), :67-92 histogram, :94-137 prefix sum, :233-294 scatter
-//   shuffle    host/partition/partitioner.cc:280-375 (through host DRAM)
-//   build      dpu/shared/kernels/hash_build.c:9-35 + hashtable.c:89-165
-//   probe      dpu/shared/kernels/hash_probe.c:9-46 + hashtable.c:167-192
-//   compose    host/join/join_dpu.cc:168-400
+// Reference behaviour (upmem/dpu_olap): the shuffle host/partition/partitioner.cc:280-375,
+// the join composition host/join/join_dpu.cc:168-400 (partition both sides, then per
+// partition build / probe / take).
 //
-// MI355X design: tuples (key, payload) are carried through 1..4 MSD radix passes
-// over wang_hash(key) until a partition's build side fits an LDS hash table
-// (8192 slots, 64 KiB, two workgroups per CU).  Each pass is
-//   hist    (per-workgroup LDS histogram -> matrix [workgroup][bucket])
-//   scan    (bucket-major exclusive scan -> cursors, next segment table)
-//   scatter (tile of 8192 tuples: LDS ranks -> LDS staging grouped by bucket ->
-//            coalesced runs written at the workgroup's cursors)
-// so the layout is exact (no capacity slack, no global atomics) and the shuffle
-// of the reference never leaves HBM.  The payload travels with the key, which
-// removes the row-id round trip of the reference (kernel_take after partition).
-// The hash table uses the LOW bits of the same hash, like the reference
-// (hashtable.c:99-101), linear probing, LDS atomicCAS insert.
-// Bound: HBM bandwidth (integer work, no MFMA).
+// Plan: (key, payload) tuples go through 1..4 MSD radix passes over wang_hash(key) until a
+// partition's build side fits an LDS table -- the direct-address table (<= 14 hash bits left,
+// 16 Ki rows per partition; two 9-bit passes at 2^32 rows) or the probing table (8192 slots).
+// Pass 0 reads the Arrow columns, as a claiming scatter without histogram when the plan has
+// two passes and the input is large; the last pass uses the capacity layout (no histogram)
+// when every workgroup owns whole segments; otherwise hist + scan + scatter (exact layout).
+// Overflowing regions or tables are detected on the device and answered by a rerun with
+// exact passes / more radix bits.  Bound: HBM bandwidth (integer work, no MFMA).
 #include "common.h"
+#include "probe_kernels.h"
+#include "radix_kernels.h"
 
 namespace olap {
-
-constexpr int kPBlock = 512;                  // 8 waves per partition workgroup
-constexpr int kPTile = 8192;                  // tuples per tile
-constexpr int kTPT = kPTile / kPBlock;        // 16 tuples per thread
-constexpr int kMaxFBits = 10;                 // <= 1024 buckets per pass
-constexpr int kMaxF = 1 << kMaxFBits;
-constexpr int kMaxPasses = 4;
-constexpr uint32_t kScatterLds = kPTile * 8 + kMaxF * 8 + (kMaxF + 4) * 4 + 64;
-
-constexpr int kJBlock = 512;
-constexpr int kJU = 4;                        // 16-B tuple vectors in flight per thread (build / probe)
-constexpr int kSlots = 8192;                  // LDS hash table slots per partition
-constexpr uint32_t kTableCap = kSlots / 4 * 3;  // max build rows (load <= 0.75, hashtable.h:55)
-constexpr uint32_t kTargetBuildRows = kSlots / 2;
-constexpr uint32_t kEmpty = 0xFFFFFFFFu;
-
-enum { SRC_COLS = 0, SRC_TUPLES = 1 };
-
-// Input of a pass: either the batched key/payload columns (pass 0) or the tuple
-// array of the previous pass cut into segments.
-struct PassSrc {
-  // SRC_COLS
-  ColView v;
-  const void* const* key_ptrs;
-  const void* const* pay_ptrs;  // may be null: payload = global row index
-  uint64_t tiles_per_block;
-  // SRC_TUPLES
-  const uint2* tuples;
-  const uint64_t* seg_off;  // [n_seg + 1]
-  uint32_t n_seg;
-  uint32_t blocks_per_seg;
-  // SRC_TUPLES, pre-split input: block k of the grid reads tuples [blk_range[2k], blk_range[2k+1])
-  // (one chunk per sender of an exchanged segment) instead of an even share of its segment
-  const uint64_t* blk_range;
-  // SRC_TUPLES, input written by the claiming scatter (k_part_scatter_claim): segment k is
-  // [k * seg_cap, k * seg_cap + min(seg_cnt[k], seg_cap)) and holds filler tuples, which are
-  // recognised by their hash: a real tuple of segment k has ((hash >> chk_shift) & chk_mask)
-  // == (k & chk_mask)
-  const uint32_t* seg_cnt;
-  uint32_t seg_cap;
-  uint32_t chk_shift;
-  uint32_t chk_mask;  // 0: every tuple in range is real
-};
-
-struct TileRange {
-  uint64_t t0, t1;    // tile ids
-  uint64_t lo, hi;    // SRC_TUPLES: tuple range of the segment
-  uint64_t a;         // SRC_TUPLES: 16-B aligned base (lo & ~1)
-  uint32_t seg;
-};
-
-template <int SRC, int TILE = kPTile>
-__device__ __forceinline__ TileRange block_tiles(const PassSrc& s) {
-  TileRange r;
-  if (SRC == SRC_COLS) {
-    r.seg = 0;
-    r.t0 = (uint64_t)blockIdx.x * s.tiles_per_block;
-    r.t1 = min(r.t0 + s.tiles_per_block, s.v.total_units);
-    if (r.t0 > r.t1) r.t0 = r.t1;
-    r.lo = r.hi = r.a = 0;
-  } else {
-    r.seg = blockIdx.x / s.blocks_per_seg;
-    if (s.blk_range) {
-      r.lo = s.blk_range[2 * (uint64_t)blockIdx.x];
-      r.hi = s.blk_range[2 * (uint64_t)blockIdx.x + 1];
-      r.a = r.lo & ~1ull;
-      r.t0 = 0;
-      r.t1 = (r.hi - r.a + TILE - 1) / TILE;
-      return r;
-    }
-    const uint32_t j = blockIdx.x - r.seg * s.blocks_per_seg;
-    if (s.seg_cnt) {
-      r.lo = (uint64_t)r.seg * s.seg_cap;
-      r.hi = r.lo + min(s.seg_cnt[r.seg], s.seg_cap);
-    } else {
-      r.lo = s.seg_off[r.seg];
-      r.hi = s.seg_off[r.seg + 1];
-    }
-    r.a = r.lo & ~1ull;
-    const uint64_t tiles = (r.hi - r.a + TILE - 1) / TILE;
-    const uint64_t q = (tiles + s.blocks_per_seg - 1) / s.blocks_per_seg;
-    r.t0 = min((uint64_t)j * q, tiles);
-    r.t1 = min(r.t0 + q, tiles);
-  }
-  return r;
-}
-
-// Batch-table entries of the batch the workgroup is currently reading: consecutive tiles
-// mostly stay in one batch (a 2 Mi-row batch is 256 tiles), so the dependent loads
-// "pointer table -> data" are paid once per batch instead of once per tile.
-struct ColsCursor {
-  uint32_t batch = 0xFFFFFFFFu;
-  const uint32_t* kp = nullptr;
-  const uint32_t* pp = nullptr;
-  uint64_t rows = 0, row0 = 0;
-  uint64_t tile = ~0ull;       // last tile located
-  uint64_t local_unit = 0;     // its index inside the batch
-  uint64_t units = 0;          // tiles of the current batch
-};
-
-// Loads one tile: kPTile / BLOCK tuples per thread, valid bits in the returned mask.
-template <int SRC, int BLOCK, bool WANT_PAYLOAD, int TILE = kPTile>
-__device__ __forceinline__ uint32_t load_tile(const PassSrc& s, const TileRange& r, uint64_t tile, ColsCursor& cur,
-                                              uint32_t (&key)[TILE / BLOCK], uint32_t (&pay)[TILE / BLOCK]) {
-  constexpr int TPT = TILE / BLOCK;
-  uint32_t mask = 0;
-  if (SRC == SRC_COLS) {
-    // tiles are visited in order: step the (batch, local tile) pair instead of locating
-    // every tile afresh (a 64-bit division or a binary search per tile and thread)
-    Loc l;
-    if (tile == cur.tile + 1 && cur.local_unit + 1 < cur.units) {
-      l.batch = cur.batch;
-      l.local_unit = cur.local_unit + 1;
-    } else {
-      l = locate(s.v, tile);
-    }
-    cur.tile = tile;
-    cur.local_unit = l.local_unit;
-    if (l.batch != cur.batch) {  // workgroup-uniform
-      cur.batch = l.batch;
-      cur.kp = (const uint32_t*)s.key_ptrs[l.batch];
-      cur.pp = s.pay_ptrs ? (const uint32_t*)s.pay_ptrs[l.batch] : nullptr;
-      cur.rows = batch_rows(s.v, l.batch);
-      cur.row0 = batch_row0(s.v, l.batch);
-      cur.units = (cur.rows + TILE - 1) / TILE;
-    }
-    const uint64_t rows = cur.rows;
-    const uint64_t r0 = l.local_unit * TILE;
-    const uint32_t n = (uint32_t)min((uint64_t)TILE, rows - r0);
-    const uint32_t* kp = cur.kp + r0;
-    const uint32_t* pp = cur.pp ? cur.pp + r0 : nullptr;
-    const uint32_t rowid0 = (uint32_t)(cur.row0 + r0);
-    const bool fast = n == TILE && ((((uintptr_t)kp) | ((uintptr_t)pp)) & 15) == 0;
-    if (fast) {
-      uint4 kv[TPT / 4], pv[TPT / 4];
-#pragma unroll
-      for (int j = 0; j < TPT / 4; ++j) kv[j] = ((const uint4*)kp)[j * BLOCK + threadIdx.x];
-      if (WANT_PAYLOAD && pp) {
-#pragma unroll
-        for (int j = 0; j < TPT / 4; ++j) pv[j] = ((const uint4*)pp)[j * BLOCK + threadIdx.x];
-      }
-#pragma unroll
-      for (int j = 0; j < TPT / 4; ++j) {
-        key[4 * j + 0] = kv[j].x;
-        key[4 * j + 1] = kv[j].y;
-        key[4 * j + 2] = kv[j].z;
-        key[4 * j + 3] = kv[j].w;
-        if (WANT_PAYLOAD) {
-          if (pp) {
-            pay[4 * j + 0] = pv[j].x;
-            pay[4 * j + 1] = pv[j].y;
-            pay[4 * j + 2] = pv[j].z;
-            pay[4 * j + 3] = pv[j].w;
-          } else {
-            const uint32_t i0 = rowid0 + (j * BLOCK + threadIdx.x) * 4;
-            pay[4 * j + 0] = i0;
-            pay[4 * j + 1] = i0 + 1;
-            pay[4 * j + 2] = i0 + 2;
-            pay[4 * j + 3] = i0 + 3;
-          }
-        }
-      }
-      mask = (1u << TPT) - 1u;
-    } else {
-#pragma unroll
-      for (int j = 0; j < TPT / 4; ++j) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const uint32_t idx = (j * BLOCK + threadIdx.x) * 4 + k;
-          const bool ok = idx < n;
-          key[4 * j + k] = ok ? kp[idx] : 0u;
-          if (WANT_PAYLOAD) pay[4 * j + k] = ok ? (pp ? pp[idx] : rowid0 + idx) : 0u;
-          mask |= (ok ? 1u : 0u) << (4 * j + k);
-        }
-      }
-    }
-  } else {
-    const uint64_t base = r.a + tile * (uint64_t)TILE;
-    if (base >= r.lo && base + TILE <= r.hi) {  // whole tile inside the segment (uniform)
-      const uint4* tv = (const uint4*)(s.tuples + base);
-#pragma unroll
-      for (int j = 0; j < TPT / 2; ++j) {
-        const uint4 t = tv[j * BLOCK + threadIdx.x];
-        key[2 * j] = t.x;
-        pay[2 * j] = t.y;
-        key[2 * j + 1] = t.z;
-        pay[2 * j + 1] = t.w;
-      }
-      return (1u << TPT) - 1u;
-    }
-#pragma unroll
-    for (int j = 0; j < TPT / 2; ++j) {
-      const uint64_t i0 = base + (uint64_t)(j * BLOCK + threadIdx.x) * 2;
-      uint4 t = make_uint4(0, 0, 0, 0);
-      if (i0 + 1 < r.hi) {
-        t = *(const uint4*)(s.tuples + i0);
-      } else if (i0 < r.hi) {  // last, odd tuple: never read past the end of a caller's array
-        const uint2 t1 = s.tuples[i0];
-        t.x = t1.x;
-        t.y = t1.y;
-      }
-      key[2 * j] = t.x;
-      pay[2 * j] = t.y;
-      key[2 * j + 1] = t.z;
-      pay[2 * j + 1] = t.w;
-      mask |= ((i0 >= r.lo && i0 < r.hi) ? 1u : 0u) << (2 * j);
-      mask |= ((i0 + 1 >= r.lo && i0 + 1 < r.hi) ? 1u : 0u) << (2 * j + 1);
-    }
-  }
-  return mask;
-}
-
-// ------------------------------------------------------------------ hist
-template <int SRC, int BLOCK, int TILE = kPTile>
-__global__ __launch_bounds__(BLOCK) void k_part_hist(PassSrc s, uint32_t shift, uint32_t fbits,
-                                                     uint32_t* hist) {
-  constexpr int TPT = TILE / BLOCK;
-  __shared__ uint32_t cl[kMaxF];
-  const uint32_t F = 1u << fbits;
-  for (uint32_t b = threadIdx.x; b < F; b += BLOCK) cl[b] = 0;
-  __syncthreads();
-  const TileRange r = block_tiles<SRC, TILE>(s);
-  ColsCursor cur;
-  for (uint64_t tile = r.t0; tile < r.t1; ++tile) {
-    uint32_t key[TPT], pay[TPT];
-    const uint32_t mask = load_tile<SRC, BLOCK, false, TILE>(s, r, tile, cur, key, pay);
-#pragma unroll
-    for (int i = 0; i < TPT; ++i) {
-      if (mask & (1u << i)) atomicAdd(&cl[(wang_hash(key[i]) >> shift) & (F - 1)], 1u);
-    }
-  }
-  __syncthreads();
-  for (uint32_t b = threadIdx.x; b < F; b += BLOCK) hist[(uint64_t)blockIdx.x * F + b] = cl[b];
-}
-
-// ------------------------------------------------------------------ scan
-// One workgroup per input segment.  hist[(seg*Bseg + blk)*F + b] (counts) is
-// replaced by the exclusive prefix over blk; seg_off_out[seg*F + b] receives the
-// absolute start of output bucket (seg, b) -- the segment table of the next pass.
-__global__ __launch_bounds__(1024) void k_part_scan(uint32_t* hist, const uint64_t* seg_off_in,
-                                                    uint64_t total_in, uint32_t n_seg, uint32_t Bseg,
-                                                    uint32_t fbits, uint64_t* seg_off_out) {
-  __shared__ uint64_t s_wave[16];
-  const uint32_t F = 1u << fbits;
-  const uint32_t seg = blockIdx.x;
-  const uint32_t b = threadIdx.x;
-  uint64_t tot = 0;
-  if (b < F) {
-    uint32_t run = 0;
-    uint32_t* col = hist + (uint64_t)seg * Bseg * F + b;
-    uint32_t blk = 0;
-    for (; blk + 4 <= Bseg; blk += 4) {  // 4 independent loads in flight
-      const uint32_t c0 = col[(uint64_t)(blk + 0) * F], c1 = col[(uint64_t)(blk + 1) * F];
-      const uint32_t c2 = col[(uint64_t)(blk + 2) * F], c3 = col[(uint64_t)(blk + 3) * F];
-      col[(uint64_t)(blk + 0) * F] = run;
-      col[(uint64_t)(blk + 1) * F] = run + c0;
-      col[(uint64_t)(blk + 2) * F] = run + c0 + c1;
-      col[(uint64_t)(blk + 3) * F] = run + c0 + c1 + c2;
-      tot += (uint64_t)c0 + c1 + c2 + c3;
-      run += c0 + c1 + c2 + c3;
-    }
-    for (; blk < Bseg; ++blk) {
-      const uint32_t c = col[(uint64_t)blk * F];
-      col[(uint64_t)blk * F] = run;
-      run += c;
-      tot += c;
-    }
-  }
-  uint64_t incl = tot;
-#pragma unroll
-  for (int o = 1; o < kWave; o <<= 1) {
-    const uint64_t y = __shfl_up(incl, o, kWave);
-    if ((int)lane_id() >= o) incl += y;
-  }
-  if (lane_id() == kWave - 1) s_wave[threadIdx.x / kWave] = incl;
-  __syncthreads();
-  uint64_t off = seg_off_in ? seg_off_in[seg] : 0;
-  for (unsigned w = 0; w < threadIdx.x / kWave; ++w) off += s_wave[w];
-  if (b < F) seg_off_out[(uint64_t)seg * F + b] = off + incl - tot;
-  if (seg == n_seg - 1 && threadIdx.x == 0)
-    seg_off_out[(uint64_t)n_seg * F] = seg_off_in ? seg_off_in[n_seg] : total_in;
-}
-
-// --------------------------------------------------------------- scatter
-template <int SRC>
-__global__ __launch_bounds__(kPBlock, 4) void k_part_scatter(PassSrc s, uint32_t shift, uint32_t fbits,
-                                                             const uint32_t* hist,
-                                                             const uint64_t* seg_off_out, uint2* out) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  uint2* stage = (uint2*)smem;                                          // kPTile tuples
-  uint64_t* gcur = (uint64_t*)(smem + kPTile * 8);                       // F cursors
-  uint32_t* cl = (uint32_t*)(smem + kPTile * 8 + kMaxF * 8);             // F + 1 counts / local starts
-  uint32_t* wtot = cl + (kMaxF + 4);                                     // 8 wave totals
-  const uint32_t F = 1u << fbits;
-  const uint32_t BPT = (F + kPBlock - 1) / kPBlock;  // bins per thread: 1 or 2
-  const TileRange r = block_tiles<SRC>(s);
-  for (uint32_t b = threadIdx.x; b < F; b += kPBlock) {
-    gcur[b] = seg_off_out[(uint64_t)r.seg * F + b] + hist[(uint64_t)blockIdx.x * F + b];
-    cl[b] = 0;
-  }
-  __syncthreads();
-  const unsigned lane = lane_id();
-  const unsigned wave = threadIdx.x / kWave;
-  ColsCursor cur;
-  for (uint64_t tile = r.t0; tile < r.t1; ++tile) {
-    uint32_t key[kTPT], pay[kTPT], br[kTPT];
-    const uint32_t mask = load_tile<SRC, kPBlock, true>(s, r, tile, cur, key, pay);
-    // (2) bucket + rank inside the bucket
-#pragma unroll
-    for (int i = 0; i < kTPT; ++i) {
-      br[i] = 0;
-      if (mask & (1u << i)) {
-        const uint32_t b = (wang_hash(key[i]) >> shift) & (F - 1);
-        br[i] = (b << 16) | atomicAdd(&cl[b], 1u);
-      }
-    }
-    __syncthreads();
-    // (3) exclusive scan of the bucket counts, in place; counts stay in registers
-    uint32_t cnt[2] = {0, 0};
-    uint32_t local = 0;
-    const uint32_t bin0 = threadIdx.x * BPT;
-    for (uint32_t q = 0; q < BPT; ++q) {
-      if (bin0 + q < F) {
-        cnt[q] = cl[bin0 + q];
-        local += cnt[q];
-      }
-    }
-    uint32_t incl = local;
-#pragma unroll
-    for (int o = 1; o < kWave; o <<= 1) {
-      const uint32_t y = __shfl_up(incl, o, kWave);
-      if ((int)lane >= o) incl += y;
-    }
-    if (lane == kWave - 1) wtot[wave] = incl;
-    __syncthreads();
-    uint32_t pre = incl - local;
-    uint32_t n_tile = 0;
-#pragma unroll
-    for (int w = 0; w < kPBlock / kWave; ++w) {
-      if ((unsigned)w < wave) pre += wtot[w];
-      n_tile += wtot[w];
-    }
-    for (uint32_t q = 0; q < BPT; ++q) {
-      if (bin0 + q < F) {
-        cl[bin0 + q] = pre;
-        pre += cnt[q];
-      }
-    }
-    __syncthreads();
-    // (4) tuples into the staging area, grouped by bucket
-#pragma unroll
-    for (int i = 0; i < kTPT; ++i) {
-      if (mask & (1u << i)) stage[cl[br[i] >> 16] + (br[i] & 0xFFFFu)] = make_uint2(key[i], pay[i]);
-    }
-    __syncthreads();
-    // (5) coalesced copy-out: consecutive lanes -> consecutive addresses inside a run
-#pragma unroll 4
-    for (uint32_t i = threadIdx.x; i < n_tile; i += kPBlock) {
-      const uint2 t = stage[i];
-      const uint32_t b = (wang_hash(t.x) >> shift) & (F - 1);
-      out[gcur[b] + (i - cl[b])] = t;
-    }
-    __syncthreads();
-    // (6) advance the cursors, clear the counts
-    for (uint32_t q = 0; q < BPT; ++q) {
-      if (bin0 + q < F) {
-        gcur[bin0 + q] += cnt[q];
-        cl[bin0 + q] = 0;
-      }
-    }
-    __syncthreads();
-  }
-}
-
-// ------------------------------------------- scatter, write-combining variant
-// Same contract as k_part_scatter, but every global store is a whole, aligned
-// 64-byte line (8 tuples = one fabric request): per bucket the workgroup keeps the
-// < 8 tuples that do not fill a line yet in LDS ("residue") and emits them together
-// with the next tile's tuples.  Only the first and the last line of a
-// (workgroup, bucket) region can be partial.  1024 threads, one workgroup per CU
-// (LDS: 64 KiB staging + 56 KiB residues + tables); the next tile's loads are
-// issued before the copy-out of the current one.
-//
-// Per bucket (bm[b]): x = start of the bucket's lines in the virtual flush index
-// space of this tile, y = start of the bucket's NEW tuples in `stage`,
-// (z,w) = 64-bit word: absolute, 8-aligned index of residue slot 0 | residue
-// count << 56 | leading slots that belong to the previous workgroup << 60.
-constexpr int kWBlock = 1024;
-
-// LINE = tuples per emitted line: 8 (64 B) for up to 1024 buckets, 16 (128 B, a whole L2
-// line; scattered 128-B lines reach ~4.8 TB/s against ~3.6 TB/s for 64-B ones,
-// profiles/r1_ubench_rand_chunk_write.txt) for up to 512 buckets -- the LDS residue buffer
-// F * (LINE - 1) * 8 B is what bounds the fan-out.
-// Geometry: BLOCK threads work on tiles of TILE tuples; BLOCK >= max buckets (one bucket per
-// owner thread).  {1024, 8192}: one workgroup per CU, up to 1024 buckets.  {512, 4096}: two
-// workgroups per CU (their phases overlap), up to 512 buckets.
-template <int LINE, int BLOCK = kWBlock, int TILE = kPTile>
-struct WcLds {
-  static constexpr int kRes = LINE - 1;
-  static constexpr int kFmax = (LINE == 8 ? 1024 : 512) < BLOCK ? (LINE == 8 ? 1024 : 512) : BLOCK;
-  static constexpr uint32_t kStage = 0;
-  static constexpr uint32_t kResOff = kStage + TILE * 8;
-  static constexpr uint32_t kBm = kResOff + kRes * kFmax * 8;
-  static constexpr uint32_t kCl = kBm + kFmax * 16;
-  static constexpr uint32_t kL2b = kCl + (kFmax + 4) * 4;
-  static constexpr uint32_t kWtot = kL2b + ((TILE + kRes * kFmax) / LINE + 2) * 2;
-  static constexpr uint32_t kBytes = ((kWtot + 15) / 16) * 16 + (BLOCK / kWave) * 8 + 64;
-};
-constexpr int kLineAlign = 16;  // capacity regions are aligned for either line size
-
-// Capacity mode (CAPM, last pass only, one workgroup per input segment): no histogram
-// pre-pass.  Output bucket (seg, b) owns the fixed region [p * cap, (p + 1) * cap) with
-// p = seg * F + b; the workgroup reports how many tuples landed there (cnt[p]) and where
-// the partition starts in the dense numbering (dense[p]).  A bucket that would outgrow
-// its region raises *overflow and drops the excess; the host then reruns the join with
-// exact (histogram) partitioning.
-struct CapOut {
-  uint32_t cap;       // tuples per region, multiple of kLineAlign
-  uint32_t* cnt;      // [n_seg * F]
-  uint64_t* dense;    // [n_seg * F]
-  unsigned long long* overflow;
-  uint64_t* seg_total;  // non-null: the input had fillers, so the segment's dense start is unknown here --
-                        // dense[] receives the start inside the segment, seg_total[seg] the segment's
-                        // tuple count, and k_dense_fix adds the segment bases afterwards
-};
-
-template <int SRC, bool CAPM, int LINE, int BLOCK = kWBlock, int TILE = kPTile>
-__global__ __launch_bounds__(BLOCK) void k_part_scatter_wc(PassSrc s, uint32_t shift, uint32_t fbits,
-                                                             const uint32_t* hist,
-                                                             const uint64_t* seg_off_out, uint2* out,
-                                                             CapOut co) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  using LDS = WcLds<LINE, BLOCK, TILE>;
-  constexpr int kWTPT = TILE / BLOCK;
-  constexpr int kLine = LINE, kRes = LINE - 1;
-  constexpr uint32_t kFld = 15u;  // residue / skip counts: 4-bit fields at bits 56 and 60
-  uint2* stage = (uint2*)(smem + LDS::kStage);
-  uint2* res = (uint2*)(smem + LDS::kResOff);        // [bucket * kRes + slot]
-  uint4* bm = (uint4*)(smem + LDS::kBm);
-  uint32_t* cl = (uint32_t*)(smem + LDS::kCl);
-  uint16_t* l2b = (uint16_t*)(smem + LDS::kL2b);     // flush line -> bucket
-  uint64_t* wtot = (uint64_t*)(smem + ((LDS::kWtot + 15) / 16) * 16);  // per-wave (count | flush << 32)
-  const uint32_t F = 1u << fbits;
-  const TileRange r = block_tiles<SRC, TILE>(s);
-  const unsigned lane = lane_id();
-  const unsigned wave = threadIdx.x / kWave;
-  const uint32_t b_own = threadIdx.x;  // BLOCK >= kMaxF: one bucket per thread
-  const bool owner = b_own < F;
-  uint64_t region = 0;  // CAPM: first tuple index of this thread's bucket region
-  if (owner) {
-    uint64_t off;
-    if (CAPM) {
-      region = ((uint64_t)r.seg * F + b_own) * co.cap;
-      off = region;
-    } else {
-      off = seg_off_out[(uint64_t)r.seg * F + b_own] + hist[(uint64_t)blockIdx.x * F + b_own];
-    }
-    const uint64_t a = off & (kLine - 1);
-    const uint64_t w = (off - a) | (a << 56) | (a << 60);
-    bm[b_own] = make_uint4(0u, 0u, (uint32_t)w, (uint32_t)(w >> 32));
-    cl[b_own] = 0;
-  }
-  __syncthreads();
-  uint32_t key[kWTPT], pay[kWTPT], nkey[kWTPT], npay[kWTPT];
-  uint32_t mask = 0, nmask = 0;
-  ColsCursor cur;
-  if (r.t0 < r.t1) mask = load_tile<SRC, BLOCK, true, TILE>(s, r, r.t0, cur, key, pay);
-  for (uint64_t tile = r.t0; tile < r.t1; ++tile) {
-    // (2) bucket + rank of every tuple
-    uint32_t br[kWTPT];
-    constexpr uint32_t kFull = (1u << kWTPT) - 1u;
-    if (mask == kFull && !s.chk_mask) {  // whole tile valid (all but the edge tiles): no per-tuple predication
-#pragma unroll
-      for (int i = 0; i < kWTPT; ++i) {
-        const uint32_t b = (wang_hash(key[i]) >> shift) & (F - 1);
-        br[i] = (b << 16) | atomicAdd(&cl[b], 1u);
-      }
-    } else {
-      const uint32_t expect = r.seg & s.chk_mask;
-#pragma unroll
-      for (int i = 0; i < kWTPT; ++i) {
-        br[i] = 0;
-        const uint32_t h = wang_hash(key[i]);
-        if (((h >> s.chk_shift) & s.chk_mask) != expect) mask &= ~(1u << i);  // a filler of the claiming scatter
-        if (mask & (1u << i)) {
-          const uint32_t b = (h >> shift) & (F - 1);
-          br[i] = (b << 16) | atomicAdd(&cl[b], 1u);
-        }
-      }
-    }
-    __syncthreads();
-    // (3) per bucket: count c, residue rr, lines to flush f; scans of (c, f)
-    uint32_t c = 0, c_app = 0, rr = 0, f = 0;
-    uint64_t w64 = 0;
-    if (owner) {
-      c = cl[b_own];
-      const uint4 m = bm[b_own];
-      w64 = ((uint64_t)m.w << 32) | m.z;
-      rr = (uint32_t)(w64 >> 56) & kFld;
-      c_app = c;
-      if (CAPM && (w64 & 0x00FFFFFFFFFFFFFFull) - region + rr + c > co.cap) {
-        c_app = 0;  // region full: drop this tile's tuples of the bucket, report
-        if (c) atomicAdd(co.overflow, 1ull);
-      }
-      f = (rr + c_app) & ~(uint32_t)(kLine - 1);
-    }
-    const uint64_t pair = (uint64_t)c | ((uint64_t)f << 32);
-    uint64_t incl = pair;
-#pragma unroll
-    for (int o = 1; o < kWave; o <<= 1) {
-      const uint64_t yv = __shfl_up(incl, o, kWave);
-      if ((int)lane >= o) incl += yv;
-    }
-    if (lane == kWave - 1) wtot[wave] = incl;
-    __syncthreads();
-    uint64_t pre = incl - pair, tot = 0;
-#pragma unroll 1
-    for (int w = 0; w < BLOCK / kWave; ++w) {
-      const uint64_t t = wtot[w];
-      if ((unsigned)w < wave) pre += t;
-      tot += t;
-    }
-    const uint32_t lstart = (uint32_t)pre, vstart = (uint32_t)(pre >> 32);
-    const uint32_t V = (uint32_t)(tot >> 32);
-    if (owner) {
-      bm[b_own] = make_uint4(vstart, lstart, (uint32_t)w64, (uint32_t)(w64 >> 32));
-      cl[b_own] = lstart;  // consecutive buckets -> consecutive banks for the scatter below
-      for (uint32_t q = 0; q < f / kLine; ++q) l2b[vstart / kLine + q] = (uint16_t)b_own;
-    }
-    __syncthreads();
-    // (4) new tuples into the staging area, grouped by bucket, rank order
-    if (mask == kFull) {
-#pragma unroll
-      for (int i = 0; i < kWTPT; ++i) stage[cl[br[i] >> 16] + (br[i] & 0xFFFFu)] = make_uint2(key[i], pay[i]);
-    } else {
-#pragma unroll
-      for (int i = 0; i < kWTPT; ++i) {
-        if (mask & (1u << i)) stage[cl[br[i] >> 16] + (br[i] & 0xFFFFu)] = make_uint2(key[i], pay[i]);
-      }
-    }
-    // next tile's loads fly during the copy-out
-    nmask = 0;
-    if (tile + 1 < r.t1) nmask = load_tile<SRC, BLOCK, true, TILE>(s, r, tile + 1, cur, nkey, npay);
-    __syncthreads();
-    // (5) copy-out: 4 consecutive lanes write one aligned 64-byte line, 16 B (2 tuples) each
-#pragma unroll 1
-    for (uint32_t v = threadIdx.x * 2; v < V; v += BLOCK * 2) {
-      const uint32_t b = l2b[v / kLine];
-      const uint4 m = bm[b];
-      const uint64_t w = ((uint64_t)m.w << 32) | m.z;
-      const uint32_t j = v - m.x;  // even
-      const uint32_t r_old = (uint32_t)(w >> 56) & kFld, skip = (uint32_t)(w >> 60) & kFld;
-      const uint2 t0 = j < r_old ? res[b * kRes + j] : stage[m.y + (j - r_old)];
-      const uint2 t1 = j + 1 < r_old ? res[b * kRes + j + 1] : stage[m.y + (j + 1 - r_old)];
-      uint2* dst = out + (w & 0x00FFFFFFFFFFFFFFull) + j;
-      if (j >= skip) {
-        *(uint4*)dst = make_uint4(t0.x, t0.y, t1.x, t1.y);
-      } else if (j + 1 >= skip) {
-        dst[1] = t1;
-      }
-    }
-    __syncthreads();
-    // (6) what is left of each bucket becomes its residue
-    if (owner) {
-      uint64_t g = w64 & 0x00FFFFFFFFFFFFFFull;
-      uint64_t skip = (w64 >> 60) & kFld;
-      uint32_t r_new;
-      if (f) {
-        const uint32_t nf = f - rr;  // new tuples that were flushed
-        r_new = rr + c_app - f;
-        for (uint32_t q = 0; q < r_new; ++q) res[b_own * kRes + q] = stage[lstart + nf + q];
-        g += f;
-        skip = 0;
-      } else {
-        for (uint32_t q = 0; q < c_app; ++q) res[b_own * kRes + rr + q] = stage[lstart + q];
-        r_new = rr + c_app;
-      }
-      const uint64_t w = g | ((uint64_t)r_new << 56) | (skip << 60);
-      bm[b_own].z = (uint32_t)w;
-      bm[b_own].w = (uint32_t)(w >> 32);
-      cl[b_own] = 0;
-    }
-    __syncthreads();
-    mask = nmask;
-#pragma unroll
-    for (int i = 0; i < kWTPT; ++i) {
-      key[i] = nkey[i];
-      pay[i] = npay[i];
-    }
-  }
-  // tail: the last, partial line of every bucket
-  uint64_t count = 0;
-  if (owner) {
-    const uint4 m = bm[b_own];
-    const uint64_t w = ((uint64_t)m.w << 32) | m.z;
-    const uint32_t r_old = (uint32_t)(w >> 56) & kFld, skip = (uint32_t)(w >> 60) & kFld;
-    for (uint32_t j = skip; j < r_old; ++j) out[(w & 0x00FFFFFFFFFFFFFFull) + j] = res[b_own * kRes + j];
-    count = (w & 0x00FFFFFFFFFFFFFFull) - region + r_old;
-  }
-  if (CAPM) {  // partition sizes and dense starts (exclusive scan over this segment's buckets)
-    uint64_t incl = count;
-#pragma unroll
-    for (int o = 1; o < kWave; o <<= 1) {
-      const uint64_t yv = __shfl_up(incl, o, kWave);
-      if ((int)lane >= o) incl += yv;
-    }
-    __syncthreads();
-    if (lane == kWave - 1) wtot[wave] = incl;
-    __syncthreads();
-    uint64_t pre = incl - count;
-#pragma unroll 1
-    for (unsigned w = 0; w < wave; ++w) pre += wtot[w];
-    if (owner) {
-      co.cnt[(uint64_t)r.seg * F + b_own] = (uint32_t)count;
-      co.dense[(uint64_t)r.seg * F + b_own] = (co.seg_total ? 0 : r.lo) + pre;
-    }
-    if (co.seg_total && threadIdx.x == 0) {
-      uint64_t total = 0;
-      for (int w = 0; w < BLOCK / kWave; ++w) total += wtot[w];
-      co.seg_total[r.seg] = total;
-    }
-  }
-}
-
-// Claiming scatter: a pass WITHOUT a histogram that any number of workgroups can run on
-// the same buckets.  Bucket (seg, b) owns the fixed region [p * cap, (p + 1) * cap),
-// p = seg * F + b.  A workgroup writes a bucket's lines into an allotment of kClaimChunk
-// tuples it claimed with ONE global atomic on the bucket's cursor (2^32 rows -> 32 M atomics,
-// spread over the buckets), and claims the next when it runs out -- a tile's flush may
-// straddle the old and the new allotment.  At the end the unused rest of each workgroup's
-// last allotment is padded with filler tuples: a key of ANOTHER bucket, which the consumer
-// pass recognises by its hash (PassSrc::chk_*), so regions need no per-chunk bookkeeping.
-// A region that would outgrow cap raises *overflow (the host reruns with exact passes).
-struct ClaimOut {
-  uint32_t cap;      // tuples per region, multiple of kClaimChunk
-  uint32_t* cursor;  // [n_seg * F], zeroed before the launch: tuples claimed per region
-  unsigned long long* overflow;
-};
-constexpr uint32_t kClaimChunk = 128;
-
-template <int SRC, int BLOCK, int TILE>
-__global__ __launch_bounds__(BLOCK) void k_part_scatter_claim(PassSrc s, uint32_t shift, uint32_t fbits, uint2* out,
-                                                                ClaimOut co) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  using LDS = WcLds<8, BLOCK, TILE>;
-  constexpr int kWTPT = TILE / BLOCK;
-  constexpr int kLine = 8, kRes = 7;
-  uint2* stage = (uint2*)(smem + LDS::kStage);
-  uint2* res = (uint2*)(smem + LDS::kResOff);
-  // bm[b]: x = vstart | lstart << 16 (this tile), y = tuple offset of the bucket's next line in
-  // its region, z = offset of the allotment claimed in this tile, w = tuples left in the
-  // current allotment | residue count << 16
-  uint4* bm = (uint4*)(smem + LDS::kBm);
-  uint32_t* cl = (uint32_t*)(smem + LDS::kCl);
-  uint16_t* l2b = (uint16_t*)(smem + LDS::kL2b);
-  uint64_t* wtot = (uint64_t*)(smem + ((LDS::kWtot + 15) / 16) * 16);
-  const uint32_t F = 1u << fbits;
-  const TileRange r = block_tiles<SRC, TILE>(s);
-  const unsigned lane = lane_id();
-  const unsigned wave = threadIdx.x / kWave;
-  const uint32_t b_own = threadIdx.x;
-  const bool owner = b_own < F;
-  const uint64_t p_own = (uint64_t)r.seg * F + b_own;
-  if (owner) {
-    bm[b_own] = make_uint4(0u, 0u, 0u, 0u);
-    cl[b_own] = 0;
-  }
-  __syncthreads();
-  uint32_t key[kWTPT], pay[kWTPT], nkey[kWTPT], npay[kWTPT];
-  uint32_t mask = 0, nmask = 0;
-  ColsCursor cur;
-  if (r.t0 < r.t1) mask = load_tile<SRC, BLOCK, true, TILE>(s, r, r.t0, cur, key, pay);
-  for (uint64_t tile = r.t0; tile < r.t1; ++tile) {
-    uint32_t br[kWTPT];
-    const uint32_t expect = r.seg & s.chk_mask;
-#pragma unroll
-    for (int i = 0; i < kWTPT; ++i) {
-      br[i] = 0;
-      const uint32_t h = wang_hash(key[i]);
-      if (((h >> s.chk_shift) & s.chk_mask) != expect) mask &= ~(1u << i);
-      if (mask & (1u << i)) {
-        const uint32_t b = (h >> shift) & (F - 1);
-        br[i] = (b << 16) | atomicAdd(&cl[b], 1u);
-      }
-    }
-    __syncthreads();
-    uint32_t c = 0, c_app = 0, rr = 0, f = 0, pos = 0, rem = 0, pos_new = 0, claimed = 0;
-    if (owner) {
-      c = cl[b_own];
-      const uint4 m = bm[b_own];
-      pos = m.y;
-      rem = m.w & 0xFFFFu;
-      rr = (m.w >> 16) & 15u;
-      c_app = c;
-      f = (rr + c) & ~(uint32_t)(kLine - 1);
-      if (f > rem) {
-        const uint32_t need = (f - rem + kClaimChunk - 1) / kClaimChunk * kClaimChunk;
-        const uint32_t got = atomicAdd(&co.cursor[p_own], need);
-        if ((uint64_t)got + need > co.cap) {  // region full: drop this tile's tuples of the bucket, report
-          atomicAdd(co.overflow, 1ull);
-          c_app = 0;
-          f = 0;
-        } else {
-          pos_new = got;
-          claimed = need;
-        }
-      }
-    }
-    const uint64_t pair = (uint64_t)c | ((uint64_t)f << 32);
-    uint64_t incl = pair;
-#pragma unroll
-    for (int o = 1; o < kWave; o <<= 1) {
-      const uint64_t yv = __shfl_up(incl, o, kWave);
-      if ((int)lane >= o) incl += yv;
-    }
-    if (lane == kWave - 1) wtot[wave] = incl;
-    __syncthreads();
-    uint64_t pre = incl - pair, tot = 0;
-#pragma unroll 1
-    for (int w = 0; w < BLOCK / kWave; ++w) {
-      const uint64_t t = wtot[w];
-      if ((unsigned)w < wave) pre += t;
-      tot += t;
-    }
-    const uint32_t lstart = (uint32_t)pre, vstart = (uint32_t)(pre >> 32);
-    const uint32_t V = (uint32_t)(tot >> 32);
-    if (owner) {
-      bm[b_own] = make_uint4(vstart | (lstart << 16), pos, pos_new, rem | (rr << 16));
-      cl[b_own] = lstart;
-      for (uint32_t q = 0; q < f / kLine; ++q) l2b[vstart / kLine + q] = (uint16_t)b_own;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < kWTPT; ++i) {
-      if (mask & (1u << i)) stage[cl[br[i] >> 16] + (br[i] & 0xFFFFu)] = make_uint2(key[i], pay[i]);
-    }
-    nmask = 0;
-    if (tile + 1 < r.t1) nmask = load_tile<SRC, BLOCK, true, TILE>(s, r, tile + 1, cur, nkey, npay);
-    __syncthreads();
-    // copy-out: 4 consecutive lanes write one aligned 64-byte line; a bucket's lines go to the
-    // rest of its old allotment first, then to the one claimed in this tile
-#pragma unroll 1
-    for (uint32_t v = threadIdx.x * 2; v < V; v += BLOCK * 2) {
-      const uint32_t b = l2b[v / kLine];
-      const uint4 m = bm[b];
-      const uint32_t j = v - (m.x & 0xFFFFu);  // even
-      const uint32_t ls = m.x >> 16, r_old = (m.w >> 16) & 15u, rem_old = m.w & 0xFFFFu;
-      const uint2 t0 = j < r_old ? res[b * kRes + j] : stage[ls + (j - r_old)];
-      const uint2 t1 = j + 1 < r_old ? res[b * kRes + j + 1] : stage[ls + (j + 1 - r_old)];
-      const uint32_t off = j < rem_old ? m.y + j : m.z + (j - rem_old);
-      *(uint4*)(out + ((uint64_t)r.seg * F + b) * co.cap + off) = make_uint4(t0.x, t0.y, t1.x, t1.y);
-    }
-    __syncthreads();
-    if (owner) {
-      uint32_t r_new;
-      if (f) {
-        const uint32_t nf = f - rr;
-        r_new = rr + c_app - f;
-        for (uint32_t q = 0; q < r_new; ++q) res[b_own * kRes + q] = stage[lstart + nf + q];
-        if (f > rem) {
-          pos = pos_new + (f - rem);
-          rem = claimed - (f - rem);
-        } else {
-          pos += f;
-          rem -= f;
-        }
-      } else {
-        for (uint32_t q = 0; q < c_app; ++q) res[b_own * kRes + rr + q] = stage[lstart + q];
-        r_new = rr + c_app;
-      }
-      bm[b_own].y = pos;
-      bm[b_own].w = rem | (r_new << 16);
-      cl[b_own] = 0;
-    }
-    __syncthreads();
-    mask = nmask;
-#pragma unroll
-    for (int i = 0; i < kWTPT; ++i) {
-      key[i] = nkey[i];
-      pay[i] = npay[i];
-    }
-  }
-  // tail: the residue goes out as one padded line, the rest of the allotment as fillers
-  if (owner) {
-    const uint4 m = bm[b_own];
-    uint32_t pos = m.y, rem = m.w & 0xFFFFu;
-    const uint32_t rr = (m.w >> 16) & 15u;
-    uint32_t filler = 0;
-    while (((wang_hash(filler) >> shift) & (F - 1)) == b_own) ++filler;  // a key of another bucket
-    uint2* region = out + p_own * co.cap;
-    bool ok = true;
-    if (rr && rem == 0) {
-      const uint32_t got = atomicAdd(&co.cursor[p_own], kClaimChunk);
-      if ((uint64_t)got + kClaimChunk > co.cap) {
-        atomicAdd(co.overflow, 1ull);
-        ok = false;
-      } else {
-        pos = got;
-        rem = kClaimChunk;
-      }
-    }
-    if (ok) {
-      if (rr) {
-        for (uint32_t j = 0; j < (uint32_t)kLine; ++j) region[pos + j] = j < rr ? res[b_own * kRes + j] : make_uint2(filler, 0u);
-        pos += kLine;
-        rem -= kLine;
-      }
-      for (uint32_t q = 0; q < rem; q += 2) *(uint4*)(region + pos + q) = make_uint4(filler, 0u, filler, 0u);
-    }
-  }
-}
-
-// Second half of the dense numbering when the input had fillers: adds to dense[seg * F + b]
-// (start inside the segment) the tuples of all earlier segments.  One workgroup per segment.
-__global__ __launch_bounds__(1024) void k_dense_fix(const uint64_t* seg_total, uint32_t F, uint64_t* dense) {
-  __shared__ uint64_t s_wave[16];
-  uint64_t part = 0;
-  for (uint32_t i = threadIdx.x; i < blockIdx.x; i += 1024) part += seg_total[i];
-  part = wave_reduce_add(part);
-  if (lane_id() == 0) s_wave[threadIdx.x / kWave] = part;
-  __syncthreads();
-  uint64_t base = 0;
-  for (int w = 0; w < 1024 / kWave; ++w) base += s_wave[w];
-  for (uint32_t b = threadIdx.x; b < F; b += 1024) dense[(uint64_t)blockIdx.x * F + b] += base;
-}
-
-// ------------------------------------------------------------ build + probe
-// counters: [0] missing keys, [1] duplicate build keys, [2] overflowing
-// partitions, [3] max build rows
-// A partitioned side: exact layout (cap == 0: partition p = [off[p], off[p+1])) or
-// capacity layout (partition p = [p * cap, p * cap + cnt[p]), dense start dense[p]).
-struct PartView {
-  const uint2* t;
-  const uint64_t* off;
-  const uint32_t* cnt;
-  const uint64_t* dense;
-  uint32_t cap;
-};
-
-__global__ __launch_bounds__(kJBlock, 4) void k_join_probe(PartView RV, PartView LV, uint32_t nparts,
-                                                           uint32_t* out_fk, uint32_t* out_y,
-                                                           uint32_t* out_x, uint32_t pair_store_ok,
-                                                           unsigned long long* counters, uint32_t* miss_bits) {
-  const uint2* R = RV.t;
-  const uint2* L = LV.t;
-  __shared__ uint32_t s_keys[kSlots];
-  __shared__ uint32_t s_vals[kSlots];
-  __shared__ uint32_t s_sp[2];  // the one key equal to the empty marker: {present, value}
-  uint32_t my_miss = 0, my_dup = 0;
-  uint64_t my_max = 0;
-  for (uint32_t p = blockIdx.x; p < nparts; p += gridDim.x) {
-    const uint64_t rlo = RV.cap ? (uint64_t)p * RV.cap : RV.off[p];
-    const uint64_t rhi = RV.cap ? rlo + RV.cnt[p] : RV.off[p + 1];
-    const uint64_t llo = LV.cap ? (uint64_t)p * LV.cap : LV.off[p];
-    const uint64_t lhi = LV.cap ? llo + LV.cnt[p] : LV.off[p + 1];
-    const uint64_t n_r = rhi - rlo, n_l = lhi - llo;
-    // output rows are dense: tuple at sparse index i goes to row i + delta
-    const uint64_t delta = (LV.cap ? LV.dense[p] : llo) - llo;
-    const uint32_t pair_store = pair_store_ok && (delta & 1) == 0;
-    if (n_r > my_max) my_max = n_r;
-    if (n_l == 0) continue;
-    if (n_r > kTableCap) {
-      if (threadIdx.x == 0) atomicAdd(&counters[2], 1ull);
-      continue;
-    }
-    for (uint32_t i = threadIdx.x; i < kSlots; i += kJBlock) s_keys[i] = kEmpty;
-    if (threadIdx.x == 0) s_sp[0] = 0;
-    __syncthreads();
-    // build: table[pk] = payload (hash_build.c:24-31; value = right payload instead of row
-    // index).  Tuples are read 16 B per lane (2 tuples) from the 16-B aligned base below the
-    // partition, kJU vectors per thread in flight.
-    {
-      const uint64_t a = rlo & ~1ull;
-      const uint32_t span = (uint32_t)(rhi - a);
-      for (uint32_t base = 0; base < span; base += kJBlock * 2 * kJU) {
-        uint4 v[kJU];
-#pragma unroll
-        for (int u = 0; u < kJU; ++u) {
-          const uint32_t i0 = base + (u * kJBlock + threadIdx.x) * 2;
-          v[u] = make_uint4(0, 0, 0, 0);
-          if (i0 < span) v[u] = *(const uint4*)(R + a + i0);  // arrays are padded by 2 tuples
-        }
-#pragma unroll
-        for (int u = 0; u < kJU; ++u) {
-          const uint64_t i0 = a + base + (uint64_t)(u * kJBlock + threadIdx.x) * 2;
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const uint32_t k = h ? v[u].z : v[u].x, val = h ? v[u].w : v[u].y;
-            if (i0 + h < rlo || i0 + h >= rhi) continue;
-            if (k == kEmpty) {
-              s_sp[1] = val;
-              if (atomicExch(&s_sp[0], 1u)) ++my_dup;
-            } else {
-              uint32_t slot = wang_hash(k) & (kSlots - 1);
-              for (uint32_t step = 0; step < kSlots; ++step) {
-                const uint32_t old = atomicCAS(&s_keys[slot], kEmpty, k);
-                if (old == kEmpty || old == k) {  // free cell, or equal key overwrites (hashtable.c:133)
-                  s_vals[slot] = val;
-                  if (old == k) ++my_dup;
-                  break;
-                }
-                slot = (slot + 1) & (kSlots - 1);
-              }
-            }
-          }
-        }
-      }
-    }
-    __syncthreads();
-    // probe (hash_probe.c:26-36) fused with the take of the right payload
-    {
-      const uint64_t a = llo & ~1ull;
-      const uint64_t span = lhi - a;
-      for (uint64_t base = 0; base < span; base += kJBlock * 2 * kJU) {
-        uint4 v[kJU];
-#pragma unroll
-        for (int u = 0; u < kJU; ++u) {
-          const uint64_t i0 = base + (uint64_t)(u * kJBlock + threadIdx.x) * 2;
-          v[u] = make_uint4(0, 0, 0, 0);
-          if (i0 < span) v[u] = *(const uint4*)(L + a + i0);
-        }
-#pragma unroll
-        for (int u = 0; u < kJU; ++u) {
-          const uint64_t i0 = a + base + (uint64_t)(u * kJBlock + threadIdx.x) * 2;
-          uint32_t xs[2] = {0, 0};
-          bool ok[2];
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const uint32_t k = h ? v[u].z : v[u].x;
-            ok[h] = i0 + h >= llo && i0 + h < lhi;
-            if (!ok[h]) continue;
-            bool hit = false;
-            if (k == kEmpty) {
-              hit = s_sp[0] != 0;
-              xs[h] = s_sp[1];
-            } else {
-              uint32_t slot = wang_hash(k) & (kSlots - 1);
-              for (uint32_t step = 0; step < kSlots; ++step) {
-                const uint32_t kk = s_keys[slot];
-                if (kk == k) {
-                  xs[h] = s_vals[slot];
-                  hit = true;
-                  break;
-                }
-                if (kk == kEmpty) break;
-                slot = (slot + 1) & (kSlots - 1);
-              }
-            }
-            if (!hit) {
-              ++my_miss;
-              if (miss_bits) atomicOr(&miss_bits[(i0 + h + delta) >> 5], 1u << ((i0 + h + delta) & 31));  // drop mode: mark the row
-            }
-          }
-          if (ok[0] && ok[1] && pair_store) {  // i0 is even: 8-byte aligned pair stores
-            const uint64_t o = i0 + delta;
-            *(uint2*)(out_fk + o) = make_uint2(v[u].x, v[u].z);
-            *(uint2*)(out_y + o) = make_uint2(v[u].y, v[u].w);
-            *(uint2*)(out_x + o) = make_uint2(xs[0], xs[1]);
-          } else {
-            const uint64_t o = i0 + delta;
-            if (ok[0]) {
-              out_fk[o] = v[u].x;
-              out_y[o] = v[u].y;
-              out_x[o] = xs[0];
-            }
-            if (ok[1]) {
-              out_fk[o + 1] = v[u].z;
-              out_y[o + 1] = v[u].w;
-              out_x[o + 1] = xs[1];
-            }
-          }
-        }
-      }
-    }
-    __syncthreads();
-  }
-  const uint64_t wm = wave_reduce_add((uint64_t)my_miss);
-  const uint64_t wd = wave_reduce_add((uint64_t)my_dup);
-  if (lane_id() == 0) {
-    if (wm) atomicAdd(&counters[0], (unsigned long long)wm);
-    if (wd) atomicAdd(&counters[1], (unsigned long long)wd);
-  }
-  if (threadIdx.x == 0) atomicMax(&counters[3], (unsigned long long)my_max);
-}
-
-// ------------------------------------------- build + probe, direct-address table
-// Every step of the Wang hash (partition.c:20-28) is invertible modulo 2^32, so DISTINCT
-// keys have DISTINCT hashes.  All keys of one final partition share the top
-// (skip + radix) hash bits; when at most kDirectBits bits remain below them, the remaining
-// bits index an LDS table without any collision -- for ANY key set, not only dense ones:
-// no probing, no compare-and-swap; an equal key simply lands on its own slot again (the
-// reference's overwrite, hashtable.c:133).  16384 slots x (key, value) = 128 KiB, one
-// workgroup of 1024 per CU; partitions hold up to 16 Ki build rows, which lets the radix
-// passes stop at 512 buckets each (two scatter workgroups per CU).
-constexpr int kDirectBits = 14;
-constexpr int kDSlots = 1 << kDirectBits;
-constexpr int kDBlock = 512;
-
-// The table does not even store keys: inside a partition the slot index IS the key (same
-// top bits + same low bits = same hash = same key), so a slot holds the payload and one
-// occupancy bit.  64 KiB values + 2 KiB bitmap: two workgroups of 512 per CU, and only the
-// bitmap needs clearing between partitions.
-__global__ __launch_bounds__(kDBlock, 4) void k_join_probe_direct(PartView RV, PartView LV, uint32_t nparts,
-                                                               uint32_t table_bits, uint32_t* out_fk,
-                                                               uint32_t* out_y, uint32_t* out_x,
-                                                               uint32_t pair_store_ok, unsigned long long* counters,
-                                                               uint32_t* miss_bits) {
-  __shared__ uint32_t s_vals[kDSlots];
-  __shared__ uint32_t s_used[kDSlots / 32];
-  const uint2* R = RV.t;
-  const uint2* L = LV.t;
-  const uint32_t slots = 1u << table_bits, smask = slots - 1;
-  uint32_t my_miss = 0, my_dup = 0;
-  uint64_t my_max = 0;
-  for (uint32_t p = blockIdx.x; p < nparts; p += gridDim.x) {
-    const uint64_t rlo = RV.cap ? (uint64_t)p * RV.cap : RV.off[p];
-    const uint64_t rhi = RV.cap ? rlo + RV.cnt[p] : RV.off[p + 1];
-    const uint64_t llo = LV.cap ? (uint64_t)p * LV.cap : LV.off[p];
-    const uint64_t lhi = LV.cap ? llo + LV.cnt[p] : LV.off[p + 1];
-    const uint64_t n_r = rhi - rlo, n_l = lhi - llo;
-    const uint64_t delta = (LV.cap ? LV.dense[p] : llo) - llo;
-    const uint32_t pair_store = pair_store_ok && (delta & 1) == 0;
-    if (n_r > my_max) my_max = n_r;
-    if (n_l == 0) continue;
-    for (uint32_t i = threadIdx.x; i < (slots + 31) / 32; i += kDBlock) s_used[i] = 0;
-    __syncthreads();
-    {  // build
-      const uint64_t a = rlo & ~1ull;
-      const uint64_t span = rhi - a;
-      for (uint64_t base = 0; base < span; base += kDBlock * 2 * kJU) {
-        uint4 v[kJU];
-#pragma unroll
-        for (int u = 0; u < kJU; ++u) {
-          const uint64_t i0 = base + (uint64_t)(u * kDBlock + threadIdx.x) * 2;
-          v[u] = make_uint4(0, 0, 0, 0);
-          if (i0 + 1 < span) {
-            v[u] = *(const uint4*)(R + a + i0);
-          } else if (i0 < span) {
-            const uint2 t1 = R[a + i0];
-            v[u].x = t1.x;
-            v[u].y = t1.y;
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < kJU; ++u) {
-          const uint64_t i0 = a + base + (uint64_t)(u * kDBlock + threadIdx.x) * 2;
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const uint32_t k = h ? v[u].z : v[u].x, val = h ? v[u].w : v[u].y;
-            if (i0 + h < rlo || i0 + h >= rhi) continue;
-            const uint32_t slot = wang_hash(k) & smask;
-            const uint32_t bit = 1u << (slot & 31);
-            if (atomicOr(&s_used[slot >> 5], bit) & bit) ++my_dup;  // equal key overwrites (hashtable.c:133)
-            s_vals[slot] = val;
-          }
-        }
-      }
-    }
-    __syncthreads();
-    {  // probe + take of the right payload
-      const uint64_t a = llo & ~1ull;
-      const uint64_t span = lhi - a;
-      for (uint64_t base = 0; base < span; base += kDBlock * 2 * kJU) {
-        uint4 v[kJU];
-#pragma unroll
-        for (int u = 0; u < kJU; ++u) {
-          const uint64_t i0 = base + (uint64_t)(u * kDBlock + threadIdx.x) * 2;
-          v[u] = make_uint4(0, 0, 0, 0);
-          if (i0 + 1 < span) {
-            v[u] = *(const uint4*)(L + a + i0);
-          } else if (i0 < span) {
-            const uint2 t1 = L[a + i0];
-            v[u].x = t1.x;
-            v[u].y = t1.y;
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < kJU; ++u) {
-          const uint64_t i0 = a + base + (uint64_t)(u * kDBlock + threadIdx.x) * 2;
-          uint32_t xs[2] = {0, 0};
-          bool ok[2];
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const uint32_t k = h ? v[u].z : v[u].x;
-            ok[h] = i0 + h >= llo && i0 + h < lhi;
-            if (!ok[h]) continue;
-            const uint32_t slot = wang_hash(k) & smask;
-            const bool hit = (s_used[slot >> 5] >> (slot & 31)) & 1u;
-            xs[h] = s_vals[slot];
-            if (!hit) {
-              ++my_miss;
-              if (miss_bits) atomicOr(&miss_bits[(i0 + h + delta) >> 5], 1u << ((i0 + h + delta) & 31));  // drop mode: mark the row
-            }
-          }
-          const uint64_t o = i0 + delta;
-          if (ok[0] && ok[1] && pair_store) {
-            *(uint2*)(out_fk + o) = make_uint2(v[u].x, v[u].z);
-            *(uint2*)(out_y + o) = make_uint2(v[u].y, v[u].w);
-            *(uint2*)(out_x + o) = make_uint2(xs[0], xs[1]);
-          } else {
-            if (ok[0]) {
-              out_fk[o] = v[u].x;
-              out_y[o] = v[u].y;
-              out_x[o] = xs[0];
-            }
-            if (ok[1]) {
-              out_fk[o + 1] = v[u].z;
-              out_y[o + 1] = v[u].w;
-              out_x[o + 1] = xs[1];
-            }
-          }
-        }
-      }
-    }
-    __syncthreads();
-  }
-  const uint64_t wm = wave_reduce_add((uint64_t)my_miss);
-  const uint64_t wd = wave_reduce_add((uint64_t)my_dup);
-  if (lane_id() == 0) {
-    if (wm) atomicAdd(&counters[0], (unsigned long long)wm);
-    if (wd) atomicAdd(&counters[1], (unsigned long long)wd);
-  }
-  if (threadIdx.x == 0) atomicMax(&counters[3], (unsigned long long)my_max);
-}
-
-__global__ __launch_bounds__(256) void k_unzip(const uint2* t, uint64_t n, uint32_t* keys, uint32_t* pay) {
-  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
-    const uint2 v = t[i];
-    keys[i] = v.x;
-    pay[i] = v.y;
-  }
-}
 
 // ------------------------------------------------------------------ host
 struct PassPlan {
@@ -1163,51 +26,6 @@ struct PassPlan {
   uint32_t bits[kMaxPasses] = {0, 0, 0, 0};
   uint32_t total_bits = 0;
 };
-
-// ---- inner-join mode: rows whose foreign key found no primary key are dropped
-constexpr uint32_t kCompactSeg = 1u << 16;  // rows per compaction segment (2048 bitmap words)
-
-// kept[s] = rows of segment s that are not marked in the miss bitmap
-__global__ __launch_bounds__(256) void k_compact_count(const uint32_t* miss_bits, uint64_t n_rows, uint32_t* kept) {
-  __shared__ uint32_t s_wave[4];
-  const uint64_t seg = blockIdx.x;
-  const uint64_t lo = seg * kCompactSeg, hi = min(n_rows, lo + kCompactSeg);
-  uint32_t marked = 0;
-  for (uint64_t w = lo / 32 + threadIdx.x; w * 32 < hi; w += 256) {
-    uint32_t bits = miss_bits[w];
-    if (hi - w * 32 < 32) bits &= (1u << (hi - w * 32)) - 1u;
-    marked += __popc(bits);
-  }
-  marked = (uint32_t)wave_reduce_add((uint64_t)marked);
-  if (lane_id() == 0) s_wave[threadIdx.x / kWave] = marked;
-  __syncthreads();
-  if (threadIdx.x == 0) kept[seg] = (uint32_t)(hi - lo) - (s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3]);
-}
-
-// dst[base[s] + rank] = src[row] for the unmarked rows of segment s, order preserved
-__global__ __launch_bounds__(256) void k_compact_rows(const uint32_t* src, const uint32_t* miss_bits, const uint64_t* base,
-                                                      uint64_t n_rows, uint32_t* dst) {
-  __shared__ uint32_t s_wave[4];
-  __shared__ uint32_t s_run;
-  const uint64_t seg = blockIdx.x;
-  const uint64_t lo = seg * kCompactSeg, hi = min(n_rows, lo + kCompactSeg);
-  if (threadIdx.x == 0) s_run = 0;
-  __syncthreads();
-  for (uint64_t r0 = lo; r0 < hi; r0 += 256) {
-    const uint64_t row = r0 + threadIdx.x;
-    const bool keep = row < hi && !((miss_bits[row >> 5] >> (row & 31)) & 1u);
-    const unsigned long long ballot = __ballot(keep);
-    const uint32_t before = __popcll(ballot & ((1ull << lane_id()) - 1ull));
-    if (lane_id() == 0) s_wave[threadIdx.x / kWave] = (uint32_t)__popcll(ballot);
-    __syncthreads();
-    uint32_t off = s_run;
-    for (unsigned w = 0; w < threadIdx.x / kWave; ++w) off += s_wave[w];
-    if (keep) dst[base[seg] + off + before] = src[row];
-    __syncthreads();
-    if (threadIdx.x == 0) s_run += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-    __syncthreads();
-  }
-}
 
 static int ceil_log2_u64(uint64_t x) {
   int l = 0;
@@ -1326,9 +144,6 @@ static bool claim_eligible(const olap_ctx* ctx, uint64_t rows, const PassPlan& p
   return kb * kClaimChunk * F <= rows / 16;
 }
 
-constexpr int kW2Block = 512;   // geometry 2 of the write-combining scatter: two workgroups per CU
-constexpr int kW2Tile = 4096;
-constexpr uint32_t kWc2Lds = WcLds<8, kW2Block, kW2Tile>::kBytes;
 
 static bool pass_uses_geometry2(const olap_ctx* ctx, uint32_t fbits) {
   return ctx->scatter_variant == 0 && ctx->wc_geometry == 2 && !ctx->line16 && fbits <= 9;

@@ -1,0 +1,356 @@
+// probe_kernels.h -- build + probe of one partition pair in LDS, and the row compaction of
+// the inner-join mode (included by join.hip only).
+//
+// Reference behaviour: dpu/shared/kernels/hash_build.c:9-35, hash_probe.c:9-46,
+// hashtable.c:89-192 (open addressing, linear probing, equal key overwrites), fused with the
+// take of the right payload (host/join/join_dpu.cc:332-362).
+#pragma once
+#include "radix_kernels.h"
+
+namespace olap {
+
+// ------------------------------------------------------------ build + probe
+// counters: [0] missing keys, [1] duplicate build keys, [2] overflowing
+// partitions, [3] max build rows
+// A partitioned side: exact layout (cap == 0: partition p = [off[p], off[p+1])) or
+// capacity layout (partition p = [p * cap, p * cap + cnt[p]), dense start dense[p]).
+struct PartView {
+  const uint2* t;
+  const uint64_t* off;
+  const uint32_t* cnt;
+  const uint64_t* dense;
+  uint32_t cap;
+};
+
+__global__ __launch_bounds__(kJBlock, 4) void k_join_probe(PartView RV, PartView LV, uint32_t nparts,
+                                                           uint32_t* out_fk, uint32_t* out_y,
+                                                           uint32_t* out_x, uint32_t pair_store_ok,
+                                                           unsigned long long* counters, uint32_t* miss_bits) {
+  const uint2* R = RV.t;
+  const uint2* L = LV.t;
+  __shared__ uint32_t s_keys[kSlots];
+  __shared__ uint32_t s_vals[kSlots];
+  __shared__ uint32_t s_sp[2];  // the one key equal to the empty marker: {present, value}
+  uint32_t my_miss = 0, my_dup = 0;
+  uint64_t my_max = 0;
+  for (uint32_t p = blockIdx.x; p < nparts; p += gridDim.x) {
+    const uint64_t rlo = RV.cap ? (uint64_t)p * RV.cap : RV.off[p];
+    const uint64_t rhi = RV.cap ? rlo + RV.cnt[p] : RV.off[p + 1];
+    const uint64_t llo = LV.cap ? (uint64_t)p * LV.cap : LV.off[p];
+    const uint64_t lhi = LV.cap ? llo + LV.cnt[p] : LV.off[p + 1];
+    const uint64_t n_r = rhi - rlo, n_l = lhi - llo;
+    // output rows are dense: tuple at sparse index i goes to row i + delta
+    const uint64_t delta = (LV.cap ? LV.dense[p] : llo) - llo;
+    const uint32_t pair_store = pair_store_ok && (delta & 1) == 0;
+    if (n_r > my_max) my_max = n_r;
+    if (n_l == 0) continue;
+    if (n_r > kTableCap) {
+      if (threadIdx.x == 0) atomicAdd(&counters[2], 1ull);
+      continue;
+    }
+    for (uint32_t i = threadIdx.x; i < kSlots; i += kJBlock) s_keys[i] = kEmpty;
+    if (threadIdx.x == 0) s_sp[0] = 0;
+    __syncthreads();
+    // build: table[pk] = payload (hash_build.c:24-31; value = right payload instead of row
+    // index).  Tuples are read 16 B per lane (2 tuples) from the 16-B aligned base below the
+    // partition, kJU vectors per thread in flight.
+    {
+      const uint64_t a = rlo & ~1ull;
+      const uint32_t span = (uint32_t)(rhi - a);
+      for (uint32_t base = 0; base < span; base += kJBlock * 2 * kJU) {
+        uint4 v[kJU];
+#pragma unroll
+        for (int u = 0; u < kJU; ++u) {
+          const uint32_t i0 = base + (u * kJBlock + threadIdx.x) * 2;
+          v[u] = make_uint4(0, 0, 0, 0);
+          if (i0 < span) v[u] = *(const uint4*)(R + a + i0);  // arrays are padded by 2 tuples
+        }
+#pragma unroll
+        for (int u = 0; u < kJU; ++u) {
+          const uint64_t i0 = a + base + (uint64_t)(u * kJBlock + threadIdx.x) * 2;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const uint32_t k = h ? v[u].z : v[u].x, val = h ? v[u].w : v[u].y;
+            if (i0 + h < rlo || i0 + h >= rhi) continue;
+            if (k == kEmpty) {
+              s_sp[1] = val;
+              if (atomicExch(&s_sp[0], 1u)) ++my_dup;
+            } else {
+              uint32_t slot = wang_hash(k) & (kSlots - 1);
+              for (uint32_t step = 0; step < kSlots; ++step) {
+                const uint32_t old = atomicCAS(&s_keys[slot], kEmpty, k);
+                if (old == kEmpty || old == k) {  // free cell, or equal key overwrites (hashtable.c:133)
+                  s_vals[slot] = val;
+                  if (old == k) ++my_dup;
+                  break;
+                }
+                slot = (slot + 1) & (kSlots - 1);
+              }
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // probe (hash_probe.c:26-36) fused with the take of the right payload
+    {
+      const uint64_t a = llo & ~1ull;
+      const uint64_t span = lhi - a;
+      for (uint64_t base = 0; base < span; base += kJBlock * 2 * kJU) {
+        uint4 v[kJU];
+#pragma unroll
+        for (int u = 0; u < kJU; ++u) {
+          const uint64_t i0 = base + (uint64_t)(u * kJBlock + threadIdx.x) * 2;
+          v[u] = make_uint4(0, 0, 0, 0);
+          if (i0 < span) v[u] = *(const uint4*)(L + a + i0);
+        }
+#pragma unroll
+        for (int u = 0; u < kJU; ++u) {
+          const uint64_t i0 = a + base + (uint64_t)(u * kJBlock + threadIdx.x) * 2;
+          uint32_t xs[2] = {0, 0};
+          bool ok[2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const uint32_t k = h ? v[u].z : v[u].x;
+            ok[h] = i0 + h >= llo && i0 + h < lhi;
+            if (!ok[h]) continue;
+            bool hit = false;
+            if (k == kEmpty) {
+              hit = s_sp[0] != 0;
+              xs[h] = s_sp[1];
+            } else {
+              uint32_t slot = wang_hash(k) & (kSlots - 1);
+              for (uint32_t step = 0; step < kSlots; ++step) {
+                const uint32_t kk = s_keys[slot];
+                if (kk == k) {
+                  xs[h] = s_vals[slot];
+                  hit = true;
+                  break;
+                }
+                if (kk == kEmpty) break;
+                slot = (slot + 1) & (kSlots - 1);
+              }
+            }
+            if (!hit) {
+              ++my_miss;
+              if (miss_bits) atomicOr(&miss_bits[(i0 + h + delta) >> 5], 1u << ((i0 + h + delta) & 31));  // drop mode: mark the row
+            }
+          }
+          if (ok[0] && ok[1] && pair_store) {  // i0 is even: 8-byte aligned pair stores
+            const uint64_t o = i0 + delta;
+            *(uint2*)(out_fk + o) = make_uint2(v[u].x, v[u].z);
+            *(uint2*)(out_y + o) = make_uint2(v[u].y, v[u].w);
+            *(uint2*)(out_x + o) = make_uint2(xs[0], xs[1]);
+          } else {
+            const uint64_t o = i0 + delta;
+            if (ok[0]) {
+              out_fk[o] = v[u].x;
+              out_y[o] = v[u].y;
+              out_x[o] = xs[0];
+            }
+            if (ok[1]) {
+              out_fk[o + 1] = v[u].z;
+              out_y[o + 1] = v[u].w;
+              out_x[o + 1] = xs[1];
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  const uint64_t wm = wave_reduce_add((uint64_t)my_miss);
+  const uint64_t wd = wave_reduce_add((uint64_t)my_dup);
+  if (lane_id() == 0) {
+    if (wm) atomicAdd(&counters[0], (unsigned long long)wm);
+    if (wd) atomicAdd(&counters[1], (unsigned long long)wd);
+  }
+  if (threadIdx.x == 0) atomicMax(&counters[3], (unsigned long long)my_max);
+}
+
+// ------------------------------------------- build + probe, direct-address table
+// Every step of the Wang hash (partition.c:20-28) is invertible modulo 2^32, so DISTINCT
+// keys have DISTINCT hashes.  All keys of one final partition share the top
+// (skip + radix) hash bits; when at most kDirectBits bits remain below them, the remaining
+// bits index an LDS table without any collision -- for ANY key set, not only dense ones:
+// no probing, no compare-and-swap; an equal key simply lands on its own slot again (the
+// reference's overwrite, hashtable.c:133).  16384 slots x (key, value) = 128 KiB, one
+// workgroup of 1024 per CU; partitions hold up to 16 Ki build rows, which lets the radix
+// passes stop at 512 buckets each (two scatter workgroups per CU).
+constexpr int kDirectBits = 14;
+constexpr int kDSlots = 1 << kDirectBits;
+constexpr int kDBlock = 512;
+
+// The table does not even store keys: inside a partition the slot index IS the key (same
+// top bits + same low bits = same hash = same key), so a slot holds the payload and one
+// occupancy bit.  64 KiB values + 2 KiB bitmap: two workgroups of 512 per CU, and only the
+// bitmap needs clearing between partitions.
+__global__ __launch_bounds__(kDBlock, 4) void k_join_probe_direct(PartView RV, PartView LV, uint32_t nparts,
+                                                               uint32_t table_bits, uint32_t* out_fk,
+                                                               uint32_t* out_y, uint32_t* out_x,
+                                                               uint32_t pair_store_ok, unsigned long long* counters,
+                                                               uint32_t* miss_bits) {
+  __shared__ uint32_t s_vals[kDSlots];
+  __shared__ uint32_t s_used[kDSlots / 32];
+  const uint2* R = RV.t;
+  const uint2* L = LV.t;
+  const uint32_t slots = 1u << table_bits, smask = slots - 1;
+  uint32_t my_miss = 0, my_dup = 0;
+  uint64_t my_max = 0;
+  for (uint32_t p = blockIdx.x; p < nparts; p += gridDim.x) {
+    const uint64_t rlo = RV.cap ? (uint64_t)p * RV.cap : RV.off[p];
+    const uint64_t rhi = RV.cap ? rlo + RV.cnt[p] : RV.off[p + 1];
+    const uint64_t llo = LV.cap ? (uint64_t)p * LV.cap : LV.off[p];
+    const uint64_t lhi = LV.cap ? llo + LV.cnt[p] : LV.off[p + 1];
+    const uint64_t n_r = rhi - rlo, n_l = lhi - llo;
+    const uint64_t delta = (LV.cap ? LV.dense[p] : llo) - llo;
+    const uint32_t pair_store = pair_store_ok && (delta & 1) == 0;
+    if (n_r > my_max) my_max = n_r;
+    if (n_l == 0) continue;
+    for (uint32_t i = threadIdx.x; i < (slots + 31) / 32; i += kDBlock) s_used[i] = 0;
+    __syncthreads();
+    {  // build
+      const uint64_t a = rlo & ~1ull;
+      const uint64_t span = rhi - a;
+      for (uint64_t base = 0; base < span; base += kDBlock * 2 * kJU) {
+        uint4 v[kJU];
+#pragma unroll
+        for (int u = 0; u < kJU; ++u) {
+          const uint64_t i0 = base + (uint64_t)(u * kDBlock + threadIdx.x) * 2;
+          v[u] = make_uint4(0, 0, 0, 0);
+          if (i0 + 1 < span) {
+            v[u] = *(const uint4*)(R + a + i0);
+          } else if (i0 < span) {
+            const uint2 t1 = R[a + i0];
+            v[u].x = t1.x;
+            v[u].y = t1.y;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kJU; ++u) {
+          const uint64_t i0 = a + base + (uint64_t)(u * kDBlock + threadIdx.x) * 2;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const uint32_t k = h ? v[u].z : v[u].x, val = h ? v[u].w : v[u].y;
+            if (i0 + h < rlo || i0 + h >= rhi) continue;
+            const uint32_t slot = wang_hash(k) & smask;
+            const uint32_t bit = 1u << (slot & 31);
+            if (atomicOr(&s_used[slot >> 5], bit) & bit) ++my_dup;  // equal key overwrites (hashtable.c:133)
+            s_vals[slot] = val;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    {  // probe + take of the right payload
+      const uint64_t a = llo & ~1ull;
+      const uint64_t span = lhi - a;
+      for (uint64_t base = 0; base < span; base += kDBlock * 2 * kJU) {
+        uint4 v[kJU];
+#pragma unroll
+        for (int u = 0; u < kJU; ++u) {
+          const uint64_t i0 = base + (uint64_t)(u * kDBlock + threadIdx.x) * 2;
+          v[u] = make_uint4(0, 0, 0, 0);
+          if (i0 + 1 < span) {
+            v[u] = *(const uint4*)(L + a + i0);
+          } else if (i0 < span) {
+            const uint2 t1 = L[a + i0];
+            v[u].x = t1.x;
+            v[u].y = t1.y;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kJU; ++u) {
+          const uint64_t i0 = a + base + (uint64_t)(u * kDBlock + threadIdx.x) * 2;
+          uint32_t xs[2] = {0, 0};
+          bool ok[2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const uint32_t k = h ? v[u].z : v[u].x;
+            ok[h] = i0 + h >= llo && i0 + h < lhi;
+            if (!ok[h]) continue;
+            const uint32_t slot = wang_hash(k) & smask;
+            const bool hit = (s_used[slot >> 5] >> (slot & 31)) & 1u;
+            xs[h] = s_vals[slot];
+            if (!hit) {
+              ++my_miss;
+              if (miss_bits) atomicOr(&miss_bits[(i0 + h + delta) >> 5], 1u << ((i0 + h + delta) & 31));  // drop mode: mark the row
+            }
+          }
+          const uint64_t o = i0 + delta;
+          if (ok[0] && ok[1] && pair_store) {
+            *(uint2*)(out_fk + o) = make_uint2(v[u].x, v[u].z);
+            *(uint2*)(out_y + o) = make_uint2(v[u].y, v[u].w);
+            *(uint2*)(out_x + o) = make_uint2(xs[0], xs[1]);
+          } else {
+            if (ok[0]) {
+              out_fk[o] = v[u].x;
+              out_y[o] = v[u].y;
+              out_x[o] = xs[0];
+            }
+            if (ok[1]) {
+              out_fk[o + 1] = v[u].z;
+              out_y[o + 1] = v[u].w;
+              out_x[o + 1] = xs[1];
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  const uint64_t wm = wave_reduce_add((uint64_t)my_miss);
+  const uint64_t wd = wave_reduce_add((uint64_t)my_dup);
+  if (lane_id() == 0) {
+    if (wm) atomicAdd(&counters[0], (unsigned long long)wm);
+    if (wd) atomicAdd(&counters[1], (unsigned long long)wd);
+  }
+  if (threadIdx.x == 0) atomicMax(&counters[3], (unsigned long long)my_max);
+}
+
+// ---- inner-join mode: rows whose foreign key found no primary key are dropped
+constexpr uint32_t kCompactSeg = 1u << 16;  // rows per compaction segment (2048 bitmap words)
+
+// kept[s] = rows of segment s that are not marked in the miss bitmap
+__global__ __launch_bounds__(256) void k_compact_count(const uint32_t* miss_bits, uint64_t n_rows, uint32_t* kept) {
+  __shared__ uint32_t s_wave[4];
+  const uint64_t seg = blockIdx.x;
+  const uint64_t lo = seg * kCompactSeg, hi = min(n_rows, lo + kCompactSeg);
+  uint32_t marked = 0;
+  for (uint64_t w = lo / 32 + threadIdx.x; w * 32 < hi; w += 256) {
+    uint32_t bits = miss_bits[w];
+    if (hi - w * 32 < 32) bits &= (1u << (hi - w * 32)) - 1u;
+    marked += __popc(bits);
+  }
+  marked = (uint32_t)wave_reduce_add((uint64_t)marked);
+  if (lane_id() == 0) s_wave[threadIdx.x / kWave] = marked;
+  __syncthreads();
+  if (threadIdx.x == 0) kept[seg] = (uint32_t)(hi - lo) - (s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3]);
+}
+
+// dst[base[s] + rank] = src[row] for the unmarked rows of segment s, order preserved
+__global__ __launch_bounds__(256) void k_compact_rows(const uint32_t* src, const uint32_t* miss_bits, const uint64_t* base,
+                                                      uint64_t n_rows, uint32_t* dst) {
+  __shared__ uint32_t s_wave[4];
+  __shared__ uint32_t s_run;
+  const uint64_t seg = blockIdx.x;
+  const uint64_t lo = seg * kCompactSeg, hi = min(n_rows, lo + kCompactSeg);
+  if (threadIdx.x == 0) s_run = 0;
+  __syncthreads();
+  for (uint64_t r0 = lo; r0 < hi; r0 += 256) {
+    const uint64_t row = r0 + threadIdx.x;
+    const bool keep = row < hi && !((miss_bits[row >> 5] >> (row & 31)) & 1u);
+    const unsigned long long ballot = __ballot(keep);
+    const uint32_t before = __popcll(ballot & ((1ull << lane_id()) - 1ull));
+    if (lane_id() == 0) s_wave[threadIdx.x / kWave] = (uint32_t)__popcll(ballot);
+    __syncthreads();
+    uint32_t off = s_run;
+    for (unsigned w = 0; w < threadIdx.x / kWave; ++w) off += s_wave[w];
+    if (keep) dst[base[seg] + off + before] = src[row];
+    __syncthreads();
+    if (threadIdx.x == 0) s_run += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    __syncthreads();
+  }
+}
+
+}  // namespace olap
