@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <unordered_set>
 #include <vector>
 
 #include "olap_gpu.h"
@@ -73,6 +74,8 @@ struct olap_ctx {
   };
   std::vector<Pending> pending;
   std::vector<hipEvent_t> event_pool;
+
+  std::unordered_set<const void*> lds_raised;  // kernels whose dynamic-LDS limit was raised on this device
 
   // join tuning
   int radix_bits_total = -1;

@@ -154,6 +154,81 @@ static uint32_t pass0_tile(const olap_ctx* ctx, const PassPlan& plan) {
   return pass_uses_geometry2(ctx, plan.bits[0]) ? kW2Tile : kPTile;
 }
 
+// ---- kernel launches.  Geometry 2 = {512 threads, 4096-tuple tiles, two workgroups per CU}; geometry 1 =
+// {1024 threads, 8192-tuple tiles}.  The scatters need more than the default 64 KiB of dynamic LDS: the limit
+// is raised once per kernel and context.
+static int allow_lds(olap_ctx* ctx, const void* kernel, uint32_t bytes) {
+  if (ctx->lds_raised.insert(kernel).second)
+    OLAP_HIP(ctx, hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return OLAP_OK;
+}
+
+template <int SRC, bool CAPM, int LINE, int BLOCK, int TILE>
+static int launch_wc(olap_ctx* ctx, unsigned blocks, const PassSrc& src, uint32_t shift, uint32_t fbits, const uint32_t* hist,
+                     const uint64_t* seg_out, uint2* out, const CapOut& co) {
+  constexpr uint32_t kLds = WcLds<LINE, BLOCK, TILE>::kBytes;
+  OLAP_TRY(allow_lds(ctx, reinterpret_cast<const void*>(k_part_scatter_wc<SRC, CAPM, LINE, BLOCK, TILE>), kLds));
+  hipLaunchKernelGGL((k_part_scatter_wc<SRC, CAPM, LINE, BLOCK, TILE>), dim3(blocks), dim3(BLOCK), kLds, ctx->stream, src, shift, fbits,
+                     hist, seg_out, out, co);
+  OLAP_HIP(ctx, hipGetLastError());
+  return OLAP_OK;
+}
+
+// write-combining scatter, exact (hist + seg_out) or capacity layout (CAPM; tuple input only)
+template <bool CAPM>
+static int launch_scatter(olap_ctx* ctx, bool cols, bool g2, bool line16, unsigned blocks, const PassSrc& src, uint32_t shift,
+                          uint32_t fbits, const uint32_t* hist, const uint64_t* seg_out, uint2* out, const CapOut& co) {
+  if constexpr (!CAPM) {
+    if (cols) {
+      if (g2) return launch_wc<SRC_COLS, false, 8, kW2Block, kW2Tile>(ctx, blocks, src, shift, fbits, hist, seg_out, out, co);
+      if (line16) return launch_wc<SRC_COLS, false, 16, kWBlock, kPTile>(ctx, blocks, src, shift, fbits, hist, seg_out, out, co);
+      return launch_wc<SRC_COLS, false, 8, kWBlock, kPTile>(ctx, blocks, src, shift, fbits, hist, seg_out, out, co);
+    }
+  }
+  if (g2) return launch_wc<SRC_TUPLES, CAPM, 8, kW2Block, kW2Tile>(ctx, blocks, src, shift, fbits, hist, seg_out, out, co);
+  if (line16) return launch_wc<SRC_TUPLES, CAPM, 16, kWBlock, kPTile>(ctx, blocks, src, shift, fbits, hist, seg_out, out, co);
+  return launch_wc<SRC_TUPLES, CAPM, 8, kWBlock, kPTile>(ctx, blocks, src, shift, fbits, hist, seg_out, out, co);
+}
+
+template <int SRC, int BLOCK, int TILE>
+static int launch_claim_as(olap_ctx* ctx, unsigned blocks, const PassSrc& src, uint32_t shift, uint32_t fbits, uint2* out,
+                           const ClaimOut& co) {
+  constexpr uint32_t kLds = WcLds<8, BLOCK, TILE>::kBytes;
+  OLAP_TRY(allow_lds(ctx, reinterpret_cast<const void*>(k_part_scatter_claim<SRC, BLOCK, TILE>), kLds));
+  hipLaunchKernelGGL((k_part_scatter_claim<SRC, BLOCK, TILE>), dim3(blocks), dim3(BLOCK), kLds, ctx->stream, src, shift, fbits, out, co);
+  OLAP_HIP(ctx, hipGetLastError());
+  return OLAP_OK;
+}
+
+static int launch_claim(olap_ctx* ctx, bool cols, bool g2, unsigned blocks, const PassSrc& src, uint32_t shift, uint32_t fbits, uint2* out,
+                        const ClaimOut& co) {
+  if (g2) return cols ? launch_claim_as<SRC_COLS, kW2Block, kW2Tile>(ctx, blocks, src, shift, fbits, out, co)
+                      : launch_claim_as<SRC_TUPLES, kW2Block, kW2Tile>(ctx, blocks, src, shift, fbits, out, co);
+  return cols ? launch_claim_as<SRC_COLS, kWBlock, kPTile>(ctx, blocks, src, shift, fbits, out, co)
+              : launch_claim_as<SRC_TUPLES, kWBlock, kPTile>(ctx, blocks, src, shift, fbits, out, co);
+}
+
+// tile-staged scatter without residues (scatter_variant = 1, A/B)
+static int launch_staged(olap_ctx* ctx, bool cols, unsigned blocks, const PassSrc& src, uint32_t shift, uint32_t fbits, const uint32_t* hist,
+                         const uint64_t* seg_out, uint2* out) {
+  if (cols) {
+    OLAP_TRY(allow_lds(ctx, reinterpret_cast<const void*>(k_part_scatter<SRC_COLS>), kScatterLds));
+    hipLaunchKernelGGL((k_part_scatter<SRC_COLS>), dim3(blocks), dim3(kPBlock), kScatterLds, ctx->stream, src, shift, fbits, hist, seg_out, out);
+  } else {
+    OLAP_TRY(allow_lds(ctx, reinterpret_cast<const void*>(k_part_scatter<SRC_TUPLES>), kScatterLds));
+    hipLaunchKernelGGL((k_part_scatter<SRC_TUPLES>), dim3(blocks), dim3(kPBlock), kScatterLds, ctx->stream, src, shift, fbits, hist, seg_out, out);
+  }
+  OLAP_HIP(ctx, hipGetLastError());
+  return OLAP_OK;
+}
+
+static void launch_hist(olap_ctx* ctx, bool cols, bool g2, unsigned blocks, const PassSrc& src, uint32_t shift, uint32_t fbits, uint32_t* hist) {
+  if (g2 && cols) hipLaunchKernelGGL((k_part_hist<SRC_COLS, kW2Block, kW2Tile>), dim3(blocks), dim3(kW2Block), 0, ctx->stream, src, shift, fbits, hist);
+  else if (g2) hipLaunchKernelGGL((k_part_hist<SRC_TUPLES, kW2Block, kW2Tile>), dim3(blocks), dim3(kW2Block), 0, ctx->stream, src, shift, fbits, hist);
+  else if (cols) hipLaunchKernelGGL((k_part_hist<SRC_COLS, kWBlock>), dim3(blocks), dim3(kWBlock), 0, ctx->stream, src, shift, fbits, hist);
+  else hipLaunchKernelGGL((k_part_hist<SRC_TUPLES, kWBlock>), dim3(blocks), dim3(kWBlock), 0, ctx->stream, src, shift, fbits, hist);
+}
+
 // Input of pass 0: the batched columns `cs`, or (tuple_in != nullptr) an array of tuple_n
 // (key, payload) tuples already in HBM -- what a rank receives from the all-to-all.
 static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, const uint2* tuple_in,
@@ -206,35 +281,6 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
     src.pay_ptrs = has_payload ? cs.dev_ptr_tables[1] : nullptr;
   }
   uint32_t consumed = skip_bits + (pre ? pre->bits : 0u);
-  OLAP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_scatter<SRC_COLS>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, kScatterLds));
-  OLAP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_scatter<SRC_TUPLES>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, kScatterLds));
-#define OLAP_WC_ATTR(SRCV, CAPV, LINEV)                                                                      \
-  OLAP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_scatter_wc<SRCV, CAPV, LINEV>),     \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, WcLds<LINEV>::kBytes))
-  OLAP_WC_ATTR(SRC_COLS, false, 8);
-  OLAP_WC_ATTR(SRC_COLS, false, 16);
-  OLAP_WC_ATTR(SRC_TUPLES, false, 8);
-  OLAP_WC_ATTR(SRC_TUPLES, false, 16);
-  OLAP_WC_ATTR(SRC_TUPLES, true, 8);
-  OLAP_WC_ATTR(SRC_TUPLES, true, 16);
-#undef OLAP_WC_ATTR
-#define OLAP_WC2_ATTR(SRCV, CAPV)                                                                                      \
-  OLAP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_scatter_wc<SRCV, CAPV, 8, kW2Block, kW2Tile>), \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, kWc2Lds))
-  OLAP_WC2_ATTR(SRC_COLS, false);
-  OLAP_WC2_ATTR(SRC_TUPLES, false);
-  OLAP_WC2_ATTR(SRC_TUPLES, true);
-#undef OLAP_WC2_ATTR
-#define OLAP_CLAIM_ATTR(SRCV, BLOCKV, TILEV, LDSV)                                                                 \
-  OLAP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_scatter_claim<SRCV, BLOCKV, TILEV>),     \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDSV))
-  OLAP_CLAIM_ATTR(SRC_COLS, kW2Block, kW2Tile, kWc2Lds);
-  OLAP_CLAIM_ATTR(SRC_TUPLES, kW2Block, kW2Tile, kWc2Lds);
-  OLAP_CLAIM_ATTR(SRC_COLS, kWBlock, kPTile, WcLds<8>::kBytes);
-  OLAP_CLAIM_ATTR(SRC_TUPLES, kWBlock, kPTile, WcLds<8>::kBytes);
-#undef OLAP_CLAIM_ATTR
   bool claimed_input = false;  // the current input was written by the claiming scatter
   const bool wc = ctx->scatter_variant == 0;  // write-combining scatter
   for (int i = 0; i < plan.passes; ++i) {
@@ -275,18 +321,7 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
       {
         PhaseScope ps(ctx, PH_PART_SCATTER);
         const ClaimOut co{ccap, cursor, d_overflow};
-        if (g2 && cols)
-          hipLaunchKernelGGL((k_part_scatter_claim<SRC_COLS, kW2Block, kW2Tile>), dim3((unsigned)blocks), dim3(kW2Block), kWc2Lds,
-                             ctx->stream, src, shift, fbits, out, co);
-        else if (g2)
-          hipLaunchKernelGGL((k_part_scatter_claim<SRC_TUPLES, kW2Block, kW2Tile>), dim3((unsigned)blocks), dim3(kW2Block), kWc2Lds,
-                             ctx->stream, src, shift, fbits, out, co);
-        else if (cols)
-          hipLaunchKernelGGL((k_part_scatter_claim<SRC_COLS, kWBlock, kPTile>), dim3((unsigned)blocks), dim3(kWBlock),
-                             WcLds<8>::kBytes, ctx->stream, src, shift, fbits, out, co);
-        else
-          hipLaunchKernelGGL((k_part_scatter_claim<SRC_TUPLES, kWBlock, kPTile>), dim3((unsigned)blocks), dim3(kWBlock),
-                             WcLds<8>::kBytes, ctx->stream, src, shift, fbits, out, co);
+        OLAP_TRY(launch_claim(ctx, cols, g2, (unsigned)blocks, src, shift, fbits, out, co));
         OLAP_HIP(ctx, hipGetLastError());
       }
       src.seg_cnt = cursor;  // the next pass reads regions of `ccap` tuples and skips the fillers
@@ -311,18 +346,8 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
         if (!seg_total) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (segment totals)");
       }
       CapOut co{so->cap, so->cnt, so->dense, d_overflow, seg_total};
-      if (g2)
-        hipLaunchKernelGGL((k_part_scatter_wc<SRC_TUPLES, true, 8, kW2Block, kW2Tile>), dim3((unsigned)blocks), dim3(kW2Block),
-                           kWc2Lds, ctx->stream, src, shift, fbits, (const uint32_t*)nullptr,
-                           (const uint64_t*)nullptr, out, co);
-      else if (fbits <= 9 && ctx->line16)
-        hipLaunchKernelGGL((k_part_scatter_wc<SRC_TUPLES, true, 16>), dim3((unsigned)blocks), dim3(kWBlock),
-                           WcLds<16>::kBytes, ctx->stream, src, shift, fbits, (const uint32_t*)nullptr,
-                           (const uint64_t*)nullptr, out, co);
-      else
-        hipLaunchKernelGGL((k_part_scatter_wc<SRC_TUPLES, true, 8>), dim3((unsigned)blocks), dim3(kWBlock),
-                           WcLds<8>::kBytes, ctx->stream, src, shift, fbits, (const uint32_t*)nullptr,
-                           (const uint64_t*)nullptr, out, co);
+      OLAP_TRY((launch_scatter<true>(ctx, /*cols=*/false, g2, fbits <= 9 && ctx->line16, (unsigned)blocks, src, shift, fbits, nullptr,
+                                     nullptr, out, co)));
       OLAP_HIP(ctx, hipGetLastError());
       if (claimed_input) {  // the segments' dense starts were unknown to the scatter: number the partitions now
         hipLaunchKernelGGL(k_dense_fix, dim3((unsigned)n_seg), dim3(1024), 0, ctx->stream, (const uint64_t*)seg_total, (uint32_t)F,
@@ -337,14 +362,7 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
     if (!hist || !seg_out) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (partition pass %d)", i);
     {
       PhaseScope ps(ctx, PH_PART_HIST);
-      if (g2 && cols)
-        hipLaunchKernelGGL((k_part_hist<SRC_COLS, kW2Block, kW2Tile>), dim3((unsigned)blocks), dim3(kW2Block), 0, ctx->stream, src, shift, fbits, hist);
-      else if (g2)
-        hipLaunchKernelGGL((k_part_hist<SRC_TUPLES, kW2Block, kW2Tile>), dim3((unsigned)blocks), dim3(kW2Block), 0, ctx->stream, src, shift, fbits, hist);
-      else if (cols)
-        hipLaunchKernelGGL((k_part_hist<SRC_COLS, kWBlock>), dim3((unsigned)blocks), dim3(kWBlock), 0, ctx->stream, src, shift, fbits, hist);
-      else
-        hipLaunchKernelGGL((k_part_hist<SRC_TUPLES, kWBlock>), dim3((unsigned)blocks), dim3(kWBlock), 0, ctx->stream, src, shift, fbits, hist);
+      launch_hist(ctx, cols, g2, (unsigned)blocks, src, shift, fbits, hist);
       OLAP_HIP(ctx, hipGetLastError());
     }
     {
@@ -355,33 +373,12 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
     }
     {
       PhaseScope ps(ctx, PH_PART_SCATTER);
-      const bool l16 = fbits <= 9 && ctx->line16;
-      if (g2 && cols)
-        hipLaunchKernelGGL((k_part_scatter_wc<SRC_COLS, false, 8, kW2Block, kW2Tile>), dim3((unsigned)blocks), dim3(kW2Block),
-                           kWc2Lds, ctx->stream, src, shift, fbits, (const uint32_t*)hist,
-                           (const uint64_t*)seg_out, out, CapOut{});
-      else if (g2)
-        hipLaunchKernelGGL((k_part_scatter_wc<SRC_TUPLES, false, 8, kW2Block, kW2Tile>), dim3((unsigned)blocks), dim3(kW2Block),
-                           kWc2Lds, ctx->stream, src, shift, fbits, (const uint32_t*)hist,
-                           (const uint64_t*)seg_out, out, CapOut{});
-      else if (wc && cols && l16)
-        hipLaunchKernelGGL((k_part_scatter_wc<SRC_COLS, false, 16>), dim3((unsigned)blocks), dim3(kWBlock), WcLds<16>::kBytes,
-                           ctx->stream, src, shift, fbits, (const uint32_t*)hist, (const uint64_t*)seg_out, out, CapOut{});
-      else if (wc && cols)
-        hipLaunchKernelGGL((k_part_scatter_wc<SRC_COLS, false, 8>), dim3((unsigned)blocks), dim3(kWBlock), WcLds<8>::kBytes,
-                           ctx->stream, src, shift, fbits, (const uint32_t*)hist, (const uint64_t*)seg_out, out, CapOut{});
-      else if (wc && l16)
-        hipLaunchKernelGGL((k_part_scatter_wc<SRC_TUPLES, false, 16>), dim3((unsigned)blocks), dim3(kWBlock), WcLds<16>::kBytes,
-                           ctx->stream, src, shift, fbits, (const uint32_t*)hist, (const uint64_t*)seg_out, out, CapOut{});
-      else if (wc)
-        hipLaunchKernelGGL((k_part_scatter_wc<SRC_TUPLES, false, 8>), dim3((unsigned)blocks), dim3(kWBlock), WcLds<8>::kBytes,
-                           ctx->stream, src, shift, fbits, (const uint32_t*)hist, (const uint64_t*)seg_out, out, CapOut{});
-      else if (cols)
-        hipLaunchKernelGGL((k_part_scatter<SRC_COLS>), dim3((unsigned)blocks), dim3(kPBlock), kScatterLds, ctx->stream,
-                           src, shift, fbits, (const uint32_t*)hist, (const uint64_t*)seg_out, out);
-      else
-        hipLaunchKernelGGL((k_part_scatter<SRC_TUPLES>), dim3((unsigned)blocks), dim3(kPBlock), kScatterLds, ctx->stream,
-                           src, shift, fbits, (const uint32_t*)hist, (const uint64_t*)seg_out, out);
+      if (wc) {
+        OLAP_TRY((launch_scatter<false>(ctx, cols, g2, fbits <= 9 && ctx->line16, (unsigned)blocks, src, shift, fbits, hist, seg_out,
+                                        out, CapOut{})));
+      } else {  // tile-staged A/B variant
+        OLAP_TRY(launch_staged(ctx, cols, (unsigned)blocks, src, shift, fbits, hist, seg_out, out));
+      }
       OLAP_HIP(ctx, hipGetLastError());
     }
     in_tuples = out;
