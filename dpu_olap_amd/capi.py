@@ -283,7 +283,10 @@ class Context:
         self._check(self.lib.olap_filter_lt(self.h, dtype, _ptr_table(ptrs), _u64_table(rows), nb, in_mem,
                                             C.cast(C.byref(thr), C.c_void_p), _ptr_table(out_ptrs), out_mem,
                                             out_rows, C.byref(total)))
-        return [out_rows[k] for k in range(nb)], total.value
+        # per-batch result lengths as a numpy view of the ctypes array (a Python list of 262144 entries would
+        # cost more than the kernel at the reference's BM_Filter shape)
+        import numpy as np
+        return np.frombuffer(out_rows, dtype=np.uint64, count=nb).copy() if nb else np.empty(0, np.uint64), total.value
 
     def sum(self, dtype: int, ptrs, rows, in_mem: int) -> int:
         out = C.c_uint64()

@@ -174,10 +174,10 @@ class FilterGpu(_Op):
         if mem == capi.MEM_HOST:
             outs = [np.empty(r, dtype=dt) for r in rows]  # worst case, filter_dpu.cc:67-83
             counts, _ = self.system_.filter_lt(code, ptrs, rows, mem, self.threshold, [o.ctypes.data for o in outs], capi.MEM_HOST)
-            return [o[:c] for o, c in zip(outs, counts)]
+            return [o[:c] for o, c in zip(outs, counts.tolist())]
         outs = [self.system_.empty(r, dt) for r in rows]
         counts, _ = self.system_.filter_lt(code, ptrs, rows, mem, self.threshold, [o.ptr for o in outs], capi.MEM_DEVICE)
-        return [DeviceArray(o.ptr, c, dt) for o, c in zip(outs, counts)]
+        return [DeviceArray(o.ptr, c, dt) for o, c in zip(outs, counts.tolist())]
 
     def Run(self) -> int:
         return int(sum((r.rows if isinstance(r, DeviceArray) else r.size) for r in self.GetResult()))
