@@ -37,3 +37,25 @@ def test_bench_multirank_on_one_gpu(world, sf):
     assert d["config"]["exchange"]["path"] == "fused" and d["scaling"] == "strong"
     assert d["config"]["radix"]["missing_keys"] == 0
     assert d["unit"] == "Mrows/s" and d["value"] > 0 and d["roofline"]["bound"] == "hbm"
+
+
+@pytest.mark.gpu
+def test_bench_ops_two_ranks_on_one_gpu():
+    """filter / sum / take shard by batch with no data-path communication: two ranks
+    share cuda:0, meet only for the barrier, the max time and the final add; results verified
+    per rank against the generator."""
+    env = dict(os.environ, OLAP_BENCH_SHARE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench_ops.py"), "--sf", "8", "--steps", "1", "--warmup", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 7                       # 1 filter + 3 sum + 3 take, printed by rank 0 only
+    for d in lines:
+        assert d["verified"] and d["n_gpus"] == 2 and "GPUs:2" in d["metric"] and d["value"] > 0
+    f = lines[0]
+    assert f["metric"].startswith("BM_FilterGpu/Batches:1024/") and abs(f["results"] / (1024 * 65536) - 0.25) < 0.01
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench_ops.py"), "--sf", "8", "--steps", "1", "--warmup", "0", "--only", "sum"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    single = [json.loads(l) for l in one.stdout.splitlines() if l.startswith("{")]
+    assert [d["result"] for d in single] == [d["result"] for d in lines[1:4]]   # the sharded sums add up to the single-GPU sums
