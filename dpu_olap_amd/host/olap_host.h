@@ -181,12 +181,18 @@ struct OutputBuffers {
   std::vector<void*> ptrs;
 };
 
+// Room for `rows[b]` elements per batch, carved out of ONE allocation (64-byte aligned slices that keep
+// the parent alive): thousands of 256 KiB allocations cost more than the GPU work, and pages a filter
+// never writes to are never touched.
 inline arrow::Result<OutputBuffers> AllocateOutputs(const std::vector<uint64_t>& rows, int width) {
   OutputBuffers out;
-  for (uint64_t r : rows) {
-    ARROW_ASSIGN_OR_RAISE(auto buf, arrow::AllocateBuffer((int64_t)std::max<uint64_t>(r, 1) * width));
-    out.ptrs.push_back(buf->mutable_data());
-    out.buffers.push_back(std::move(buf));
+  std::vector<int64_t> offset(rows.size() + 1, 0);
+  for (size_t b = 0; b < rows.size(); ++b) offset[b + 1] = offset[b] + (((int64_t)std::max<uint64_t>(rows[b], 1) * width + 63) & ~int64_t(63));
+  ARROW_ASSIGN_OR_RAISE(std::shared_ptr<arrow::Buffer> parent, arrow::AllocateBuffer(std::max<int64_t>(offset.back(), 64)));
+  for (size_t b = 0; b < rows.size(); ++b) {
+    auto slice = arrow::SliceMutableBuffer(parent, offset[b], (int64_t)std::max<uint64_t>(rows[b], 1) * width);
+    out.ptrs.push_back(slice->mutable_data());
+    out.buffers.push_back(std::move(slice));
   }
   return out;
 }
