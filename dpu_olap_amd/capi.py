@@ -276,7 +276,7 @@ class Context:
     # -- operators (raw pointer level)
     def filter_lt(self, dtype: int, ptrs, rows, in_mem: int, threshold, out_ptrs, out_mem: int):
         nb = len(ptrs)
-        ct = {U32: C.c_uint32, I32: C.c_int32, U64: C.c_uint64, I64: C.c_int64}[dtype]
+        ct = {U32: C.c_uint32, I32: C.c_int32, U64: C.c_uint64, I64: C.c_int64}.get(dtype, C.c_uint64)  # unknown codes are the ABI's to refuse
         thr = ct(threshold)
         out_rows = (C.c_uint64 * max(nb, 1))()
         total = C.c_uint64()

@@ -1007,3 +1007,37 @@ def test_join_random_shapes_and_plans_vs_oracle(dev, seed):
     assert got[0].size == fk.size, (knobs, bits, j.stats)
     for g, e in zip(got, exp):
         np.testing.assert_array_equal(g, e, err_msg=f"{knobs} bits={bits} stats={j.stats}")
+
+
+# ------------------------------------------------------------ error behaviour
+def test_c_abi_rejects_misuse_with_status_codes(dev):
+    """The ABI never throws or aborts: misuse comes back as a negative status
+    plus a message, and the context stays usable."""
+    from dpu_olap_amd import capi
+    a = np.arange(1000, dtype=np.uint32)
+    d = dev.to_device(a)
+    out = dev.empty(1000, "uint32")
+
+    def code(fn):
+        with pytest.raises(capi.OlapError) as e:
+            fn()
+        assert e.value.message
+        return e.value.code
+
+    assert code(lambda: dev.filter_lt(99, [d.ptr], [1000], capi.MEM_DEVICE, 5, [out.ptr], capi.MEM_DEVICE)) == capi.ERR_INVALID    # dtype
+    assert code(lambda: dev.filter_lt(capi.U32, [d.ptr], [1000], 7, 5, [out.ptr], capi.MEM_DEVICE)) == capi.ERR_INVALID          # memory space
+    assert code(lambda: dev.filter_lt(capi.U32, [d.ptr], [1000], capi.MEM_DEVICE, 5, [0], capi.MEM_DEVICE)) == capi.ERR_INVALID   # null output
+    assert code(lambda: dev.filter_lt(capi.U64, [d.ptr + 4], [100], capi.MEM_DEVICE, 5, [out.ptr], capi.MEM_DEVICE)) == capi.ERR_INVALID  # misaligned
+    assert code(lambda: dev.partition_u32([d.ptr], None, [1000], capi.MEM_DEVICE, 3, out.ptr, out.ptr, 1000, capi.MEM_DEVICE)) == capi.ERR_INVALID  # P not 2^k
+    assert code(lambda: dev.partition_u32([d.ptr], None, [1000], capi.MEM_DEVICE, 4, out.ptr, out.ptr, 10, capi.MEM_DEVICE)) == capi.ERR_CAPACITY
+    assert code(lambda: dev.join_u32([d.ptr], [d.ptr], [1000], [d.ptr], [d.ptr], [1000], capi.MEM_DEVICE, out.ptr, out.ptr, out.ptr, 10,
+                                     capi.MEM_DEVICE)) == capi.ERR_CAPACITY
+    assert code(lambda: dev.join_tuples_u32(d.ptr + 8, 10, d.ptr, 10, out.ptr, out.ptr, out.ptr, 1000)) == capi.ERR_INVALID            # 16-byte alignment
+    assert code(lambda: dev.join_presplit_u32(d.ptr, 10, [0, 5], [5, 99], d.ptr, 10, [0, 5], [5, 10], 2, 1, out.ptr, out.ptr, out.ptr,
+                                              1000)) == capi.ERR_INVALID                                                               # chunk outside the array
+    assert code(lambda: dev.join_configure(31, 0)) == capi.ERR_INVALID
+    assert code(lambda: dev.set_tuning("no_such_knob", 1)) == capi.ERR_INVALID
+    assert code(lambda: dev.join_set_hash_skip_bits(40)) == capi.ERR_INVALID
+    # the context still works
+    counts, total = dev.filter_lt(capi.U32, [d.ptr], [1000], capi.MEM_DEVICE, 10, [out.ptr], capi.MEM_DEVICE)
+    assert total == 10 and int(counts[0]) == 10
