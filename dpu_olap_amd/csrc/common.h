@@ -81,7 +81,6 @@ struct olap_ctx {
   int radix_bits_total = -1;
   int max_bits_per_pass = 0;
   int scatter_variant = 0;  // 0 write-combining scatter, 1 tile-staged scatter (A/B)
-  int probe_variant = 0;
   int take_variant = 0;    // 0 auto, 1 never use the LDS-window kernel, 2 never use small tiles
   int line16 = 0;          // 1: 128-byte write-combining lines for passes of <= 512 buckets (measured: no gain yet, the kernel is not write-bound there)
   int direct_table = 1;    // collision-free direct-address LDS table when <= 14 hash bits remain (0: always probe)

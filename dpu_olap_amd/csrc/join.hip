@@ -685,10 +685,6 @@ int olap_set_tuning(olap_ctx* ctx, const char* key, int value) {
     ctx->host_copy_threads = value;
     return OLAP_OK;
   }
-  if (!std::strcmp(key, "probe_variant")) {
-    ctx->probe_variant = value;
-    return OLAP_OK;
-  }
   return ctx->fail(OLAP_ERR_INVALID, "unknown tuning key '%s'", key);
 }
 

@@ -237,11 +237,21 @@ int olap_join_set_unmatched(olap_ctx* ctx, int mode);
  * called, and its transfer overlaps the left table's radix pass.  NULL clears it. */
 int olap_join_set_right_ready_event(olap_ctx* ctx, void* hip_event);
 
-/* Tuning knobs (0 = default).  radix_bits_total < 0 keeps the automatic choice
- * ceil(log2(right_rows / 4096)). */
+/* Radix plan override.  radix_bits_total < 0 keeps the automatic choice: 18 - skip bits
+ * (16 Ki-row partitions, direct-address LDS table) for large build sides, else
+ * ceil(log2(right_rows / 4096)) (probing table); max_bits_per_pass 0 = up to 10. */
 int olap_join_configure(olap_ctx* ctx, int radix_bits_total, int max_bits_per_pass);
-/* Kernel-variant switches for A/B measurements in one process ("scatter_variant":
- * 0 = write-combining scatter (default), 1 = tile-staged scatter). */
+/* Kernel-variant switches for A/B measurements in one process; every combination gives the same
+ * rows (tests/test_gpu_parity.py::test_join_random_shapes_and_plans_vs_oracle).
+ *   scatter_variant    0 write-combining scatter (default) | 1 tile-staged scatter
+ *   wc_geometry        2 two 512-thread workgroups per CU for passes of <= 512 buckets (default) | 1 one of 1024
+ *   line16             0 64-byte lines (default) | 1 128-byte lines for passes of <= 512 buckets (one workgroup per CU)
+ *   capacity_mode      1 last pass without histogram, fixed-capacity regions (default) | 0 exact layout
+ *   claim_mode         1 pass 0 of large two-pass plans as a claiming scatter (default) | 0 never | 2 always
+ *   direct_table       1 direct-address LDS table when <= 14 hash bits remain (default) | 0 probing table
+ *   take_variant       0 automatic | 1 never the LDS-window kernel | 2 never small tiles
+ *   host_stage         1 pinned ring + copy threads for OLAP_MEM_HOST operands (default) | 0 plain hipMemcpyAsync
+ *   host_copy_threads  0 = min(hardware threads, 8) */
 int olap_set_tuning(olap_ctx* ctx, const char* key, int value);
 /* Multi-GPU: when the inputs of this context were already split by the top
  * `bits` bits of wang_hash(key) (olap_partition_u32 with nr_partitions = #GPUs,
