@@ -242,7 +242,7 @@ int olap_join_set_right_ready_event(olap_ctx* ctx, void* hip_event);
  * ceil(log2(right_rows / 4096)) (probing table); max_bits_per_pass 0 = up to 10. */
 int olap_join_configure(olap_ctx* ctx, int radix_bits_total, int max_bits_per_pass);
 /* Kernel-variant switches for A/B measurements in one process; every combination gives the same
- * rows (tests/test_gpu_parity.py::test_join_random_shapes_and_plans_vs_oracle).
+ * rows (covered by the randomized shape / plan / variant test in tests/test_gpu_parity.py).
  *   scatter_variant    0 write-combining scatter (default) | 1 tile-staged scatter
  *   wc_geometry        2 two 512-thread workgroups per CU for passes of <= 512 buckets (default) | 1 one of 1024
  *   line16             0 64-byte lines (default) | 1 128-byte lines for passes of <= 512 buckets (one workgroup per CU)
