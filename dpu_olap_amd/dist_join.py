@@ -41,6 +41,8 @@ class GpuLocalOps:
     carry the uint32 bit patterns; torch is only the allocator and the RCCL front end)."""
 
     overlap_right_exchange = True   # fused path: the left table's radix pass runs under the right table's exchange
+    left_slices = 2                 # fused path: the left table is split and shipped in this many input slices, so the
+                                    # links start working after 1/left_slices of the split instead of all of it
 
     def __init__(self, ctx: capi.Context, device: torch.device):
         self.ctx = ctx
@@ -89,7 +91,8 @@ class GpuLocalOps:
         radix pass reads the chunks in place (olap_join_presplit_u32).  right_ready: an event
         recorded behind the right table's exchange -- the left table's pass then runs while the
         right table is still arriving."""
-        n = int(lt.numel())
+        l_ptr, l_span, l_lo, l_hi, n = self._span(lt, l_lo, l_hi)
+        r_ptr, r_span, r_lo, r_hi, _ = self._span(rt, r_lo, r_hi)
         out = [self.empty(n) for _ in range(3)]
         if right_ready is None:
             torch.cuda.current_stream(self.device).synchronize()  # inputs come from torch's stream; do not wait for RCCL's
@@ -97,12 +100,40 @@ class GpuLocalOps:
             self.ctx.join_set_right_ready_event(right_ready.cuda_event)
         self.ctx.join_set_hash_skip_bits(skip_bits)
         try:
-            got, stats = self.ctx.join_presplit_u32(lt.data_ptr(), n, l_lo, l_hi, rt.data_ptr(), int(rt.numel()), r_lo, r_hi,
+            got, stats = self.ctx.join_presplit_u32(l_ptr, l_span, l_lo, l_hi, r_ptr, r_span, r_lo, r_hi,
                                                     n_segments, chunks, out[0].data_ptr(), out[1].data_ptr(),
                                                     out[2].data_ptr(), n)
         finally:
             self.ctx.join_set_hash_skip_bits(0)
         return out[0][:got], out[1][:got], out[2][:got], stats
+
+    @staticmethod
+    def _span(buffers, lo, hi):
+        """A table given as one tensor, or as several received one after the other (chunk indices then count
+        through their concatenation): -> (base pointer, tuples spanned, chunk lo / hi relative to the base,
+        rows).  Separate buffers are NOT copied together: the chunks are re-based on the lowest address, and
+        whatever lies between the buffers is never read."""
+        rows = sum(h - l for l, h in zip(lo, hi))
+        if isinstance(buffers, torch.Tensor):
+            return buffers.data_ptr(), int(buffers.numel()), lo, hi, rows
+        bufs = [b for b in buffers]
+        if len(bufs) == 1:
+            return bufs[0].data_ptr(), int(bufs[0].numel()), lo, hi, rows
+        base = min(b.data_ptr() for b in bufs)
+        starts, v = [], 0                       # virtual start of every buffer in the concatenation
+        for b in bufs:
+            starts.append(v)
+            v += int(b.numel())
+        shift = [(b.data_ptr() - base) // 8 - st for b, st in zip(bufs, starts)]
+        import bisect
+        which = lambda pos: max(0, bisect.bisect_right(starts, pos) - 1)
+        nlo, nhi = [], []
+        for l, h in zip(lo, hi):
+            k = which(l if h > l else max(l - 1, 0))
+            nlo.append(l + shift[k])
+            nhi.append(h + shift[k])
+        span = max((b.data_ptr() - base) // 8 + int(b.numel()) for b in bufs)
+        return base, span, nlo, nhi, rows
 
     def join(self, lfk, ly, rpk, rx, skip_bits: int = 0):
         lrows = [int(t.numel()) for t in lfk]
@@ -193,6 +224,19 @@ def _chunk_tables(cnt: torch.Tensor):
     return [int(v) for v in lo], [int(v) for v in hi]
 
 
+def _spread(lo, hi, S: int, world: int, H: int):
+    """Re-index a (segment, sender) chunk table as (segment, H x world) with empty chunks in the extra places."""
+    if H == 1:
+        return lo, hi
+    nlo, nhi = [0] * (S * H * world), [0] * (S * H * world)
+    for j in range(S):
+        for q in range(world):
+            nlo[j * H * world + q], nhi[j * H * world + q] = lo[j * world + q], hi[j * world + q]
+        for k in range(world, H * world):
+            nlo[j * H * world + k] = nhi[j * H * world + k] = hi[j * world + world - 1]
+    return nlo, nhi
+
+
 def _fused_side(ops, keys, payload, world: int, S: int, group, async_op: bool):
     """Split one table into world x S buckets (owner = top bits, sub-bucket = next bits), ship
     every owner its S runs as one message, and return (pending tuples, chunk lo, chunk hi,
@@ -228,21 +272,36 @@ def distributed_join(ops, left_batches: Sequence, right_batches: Sequence, group
         # place.  The left table's exchange overlaps the split of the right table.
         S = (1 << FUSED_SPLIT_BITS) // world
         t0 = time.perf_counter()
-        pend_l, l_lo, l_hi, l_in, l_out = _fused_side(ops, lfk, ly, world, S, group, async_op=True)
+        # the left table goes out in H input slices: slice h's exchange runs while slice h + 1 is being split
+        H = max(1, min(int(getattr(ops, "left_slices", 1)), len(lfk)))
+        cuts = [len(lfk) * h // H for h in range(H + 1)]
+        sides = [_fused_side(ops, lfk[cuts[h]:cuts[h + 1]], ly[cuts[h]:cuts[h + 1]], world, S, group, async_op=True) for h in range(H)]
+        l_in = [sum(sd[3][p] for sd in sides) for p in range(world)]
+        l_out = [sum(sd[4][p] for sd in sides) for p in range(world)]
+        # segment j = chunks (slice h, sender q), numbered through the concatenation of the H receive buffers
+        l_lo, l_hi, v = [0] * (S * H * world), [0] * (S * H * world), 0
+        for h, sd in enumerate(sides):
+            for j in range(S):
+                for q in range(world):
+                    k = j * (H * world) + h * world + q
+                    l_lo[k], l_hi[k] = v + sd[1][j * world + q], v + sd[2][j * world + q]
+            v += sum(sd[4])
         t1 = time.perf_counter()   # left split + counts done, left tuples in flight
         overlap = getattr(ops, "overlap_right_exchange", False)
         pend_r, r_lo, r_hi, r_in, r_out = _fused_side(ops, rpk, rx, world, S, group, async_op=overlap)
-        RL = pend_l.wait()
-        if RL.is_cuda:
-            torch.cuda.current_stream(RL.device).synchronize()   # the left table has arrived
+        RL = [sd[0].wait() for sd in sides]
+        if RL[0].is_cuda:
+            torch.cuda.current_stream(RL[0].device).synchronize()   # the left table has arrived
         ready = None
         RR = pend_r.wait()          # RCCL: orders torch's stream behind the transfer, does not block the host
         if overlap and RR.is_cuda:
             ready = torch.cuda.Event()
             ready.record(torch.cuda.current_stream(RR.device))
         t2 = time.perf_counter()   # right split done; exchanges done (or, overlapped, the right one still in flight)
-        fk, y, x, stats = (ops.join_presplit(RL, l_lo, l_hi, RR, r_lo, r_hi, S, world, g, right_ready=ready) if ready is not None
-                           else ops.join_presplit(RL, l_lo, l_hi, RR, r_lo, r_hi, S, world, g))
+        r_lo, r_hi = _spread(r_lo, r_hi, S, world, H)   # both sides use H x world chunks per segment (the right one: empty extras)
+        RLx = RL if H > 1 else RL[0]
+        fk, y, x, stats = (ops.join_presplit(RLx, l_lo, l_hi, RR, r_lo, r_hi, S, H * world, g, right_ready=ready) if ready is not None
+                           else ops.join_presplit(RLx, l_lo, l_hi, RR, r_lo, r_hi, S, H * world, g))
         t3 = time.perf_counter()
         sent = sum(l_in) + sum(r_in) - l_in[rank] - r_in[rank]
         wall = {"split_left+counts": (t1 - t0) * 1e3, "split_right+exchanges": (t2 - t1) * 1e3, "local_join": (t3 - t2) * 1e3}

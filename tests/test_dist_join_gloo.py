@@ -65,11 +65,16 @@ class OracleFusedOps(OracleTupleOps):
     radix pass).  Checks the chunk tables it is handed: chunk (j, q) must hold only keys
     whose hash has owner bits = this rank and sub-bucket bits = j."""
 
+    left_slices = 2   # like GpuLocalOps: the left table is shipped in two input slices
+
+
     def join_presplit(self, lt, l_lo, l_hi, rt, r_lo, r_hi, n_segments, chunks, skip_bits=0):
         rank = dist.get_rank()
         sbits = n_segments.bit_length() - 1
 
         def gather(t, lo, hi):
+            if isinstance(t, (list, tuple)):       # several receive buffers: chunk indices count through their concatenation
+                t = torch.cat(list(t)) if len(t) else torch.empty(0, dtype=torch.int64)
             z = t.contiguous().numpy().view(np.uint64)
             assert len(lo) == len(hi) == n_segments * chunks
             assert sum(h - l for l, h in zip(lo, hi)) == z.size, "chunks must tile the received buffer"
@@ -114,7 +119,7 @@ def _worker(rank, world, port, case, outdir, tuple_path):
         ops = {"fused": OracleFusedOps, "tuple": OracleTupleOps, "cols": OracleLocalOps}[tuple_path]()
         ofk, oy, ox, info = distributed_join(ops, left, right)
         if tuple_path == "fused":
-            assert info["path"] == "fused" and info["stats"]["presplit"] == (512 // world, world)
+            assert info["path"] == "fused" and info["stats"]["presplit"] == (512 // world, 2 * world)
         u = lambda tt: tt.contiguous().numpy().view(np.uint32)
         np.savez(os.path.join(outdir, f"rank{rank}.npz"), fk=u(ofk), y=u(oy), x=u(ox),
                  sent=np.array([info["sent_rows"]]), skip=np.array([info["stats"]["skip_bits"]]))
