@@ -28,7 +28,7 @@ EXPORTS = [
     "olap_set_stream", "olap_get_stream", "olap_synchronize", "olap_reserve_workspace",
     "olap_workspace_bytes", "olap_malloc", "olap_free", "olap_memcpy_h2d", "olap_memcpy_d2h",
     "olap_memset", "olap_set_profiling", "olap_reset_timers", "olap_get_timers", "olap_filter_lt",
-    "olap_sum", "olap_take", "olap_partition_u32", "olap_partition_tuples_u32", "olap_join_u32", "olap_join_tuples_u32", "olap_join_presplit_u32", "olap_join_set_right_ready_event", "olap_join_set_unmatched", "olap_join_configure", "olap_join_set_hash_skip_bits", "olap_set_tuning",
+    "olap_sum", "olap_take", "olap_partition_u32", "olap_partition_tuples_u32", "olap_split_tuples_u32", "olap_join_u32", "olap_join_tuples_u32", "olap_join_presplit_u32", "olap_join_set_right_ready_event", "olap_join_set_unmatched", "olap_join_configure", "olap_join_set_hash_skip_bits", "olap_set_tuning",
     "olap_gen_uniform_u32", "olap_gen_uniform_u64", "olap_gen_index_u32", "olap_gen_fk_u32",
     "olap_gen_uniform_u32_at", "olap_checksum", "olap_checksum_rows3_u32",
 ]
@@ -132,6 +132,7 @@ def load_library(path: str | None = None) -> C.CDLL:
         "olap_join_u32": (i, [vp, pvp, pvp, pu64, u64, pvp, pvp, pu64, u64, i, vp, vp, vp, u64, i, pu64,
                               C.POINTER(JoinStats)]),
         "olap_partition_tuples_u32": (i, [vp, pvp, pvp, pu64, u64, i, u32, vp, u64, pu64]),
+        "olap_split_tuples_u32": (i, [vp, pvp, pvp, pu64, u64, i, u32, u32, u32, vp, u64, pu64]),
         "olap_join_tuples_u32": (i, [vp, vp, u64, vp, u64, vp, vp, vp, u64, pu64, C.POINTER(JoinStats)]),
         "olap_join_presplit_u32": (i, [vp, vp, u64, pu64, pu64, vp, u64, pu64, pu64, u32, u32, vp, vp, vp, u64, pu64,
                                        C.POINTER(JoinStats)]),
@@ -315,6 +316,16 @@ class Context:
         self._check(self.lib.olap_partition_tuples_u32(self.h, _ptr_table(key_ptrs), pay, _u64_table(rows), len(key_ptrs),
                                                        in_mem, nr_partitions, out_tuples, out_capacity, offs))
         return [offs[k] for k in range(nr_partitions + 1)]
+
+    def split_tuples_u32(self, key_ptrs, payload_ptrs, rows, in_mem: int, owner_bits: int, group_bits: int, low_bits: int,
+                         out_tuples: int, out_capacity: int):
+        """The multi-device split: buckets [owner | group | low] of the hash, laid out [group | owner | low]."""
+        nb = 1 << (owner_bits + group_bits + low_bits)
+        offs = (C.c_uint64 * (nb + 1))()
+        pay = _ptr_table(payload_ptrs) if payload_ptrs is not None else None
+        self._check(self.lib.olap_split_tuples_u32(self.h, _ptr_table(key_ptrs), pay, _u64_table(rows), len(key_ptrs), in_mem,
+                                                   owner_bits, group_bits, low_bits, out_tuples, out_capacity, offs))
+        return [offs[k] for k in range(nb + 1)]
 
     def join_tuples_u32(self, left_tuples: int, n_left: int, right_tuples: int, n_right: int, out_fk: int, out_y: int,
                         out_x: int, out_capacity: int):

@@ -64,6 +64,11 @@ static uint64_t seg_blocks(const olap_ctx* ctx, uint64_t n_seg) {
 // segment j fixes `bits` = log2(n_seg) bits and is the union of `chunks` chunks
 // [lo[j*chunks + c], hi[j*chunks + c]) of the tuple array -- one chunk per sender after
 // the fused owner + sub-bucket exchange.  Host arrays.
+// Bucket order of a single-pass split: hash fields [owner | group | low] emitted as [group | owner | low].
+struct BucketOrder {
+  uint32_t owner_bits = 0, group_bits = 0, low_bits = 0;
+};
+
 struct Presplit {
   uint32_t n_seg = 0;
   uint32_t chunks = 0;
@@ -85,6 +90,7 @@ static uint64_t side_scratch_bytes(const olap_ctx* ctx, uint64_t rows, uint64_t 
     uint64_t blocks;
     if (i == 0 && pre) {
       blocks = n_seg * pre->chunks;
+      if (blocks < (uint64_t)ctx->compute_units * 4) blocks = (uint64_t)ctx->compute_units * 4;  // chunks read by several workgroups
     } else if (i == 0) {
       blocks = (uint64_t)ctx->compute_units * 2;
       if (blocks > tiles) blocks = tiles;
@@ -234,7 +240,7 @@ static void launch_hist(olap_ctx* ctx, bool cols, bool g2, unsigned blocks, cons
 static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, const uint2* tuple_in,
                           uint64_t tuple_n, const PassPlan& plan, uint32_t skip_bits, uint2* tmp0, uint2* tmp1,
                           uint2* final_tuples, bool capm, unsigned long long* d_overflow, SideOut* so,
-                          const Presplit* pre = nullptr, bool claim = false) {
+                          const Presplit* pre = nullptr, bool claim = false, const BucketOrder* order = nullptr) {
   const uint64_t rows = tuple_in ? tuple_n : cs.view.total_rows;
   PassSrc src{};
   uint64_t n_seg = 1;
@@ -280,6 +286,13 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
     src.key_ptrs = cs.dev_ptr_tables[0];
     src.pay_ptrs = has_payload ? cs.dev_ptr_tables[1] : nullptr;
   }
+  if (order && order->group_bits) {
+    if (plan.passes != 1 || plan.bits[0] != order->owner_bits + order->group_bits + order->low_bits)
+      return ctx->fail(OLAP_ERR_INVALID, "a grouped bucket order needs a single pass over all of its bits");
+    src.ord_owner_bits = order->owner_bits;
+    src.ord_group_bits = order->group_bits;
+    src.ord_low_bits = order->low_bits;
+  }
   uint32_t consumed = skip_bits + (pre ? pre->bits : 0u);
   bool claimed_input = false;  // the current input was written by the claiming scatter
   const bool wc = ctx->scatter_variant == 0;  // write-combining scatter
@@ -303,8 +316,14 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
       if (blocks == 0) blocks = 1;
       bseg = blocks;
     } else {
-      const bool ranged = pre_ranges && i == 0;  // one workgroup per chunk of the pre-split input
-      bseg = ranged ? pre->chunks : (capm && i == plan.passes - 1) ? 1 : seg_blocks(ctx, n_seg);
+      const bool ranged = pre_ranges && i == 0;  // pre-split input: every chunk is read by chunk_split workgroups
+      uint32_t chunk_split = 1;
+      if (ranged) {
+        const uint64_t want = (uint64_t)ctx->compute_units * 2, have = n_seg * pre->chunks;
+        while (have * chunk_split < want && chunk_split < 64) chunk_split *= 2;
+      }
+      src.chunk_split = chunk_split;
+      bseg = ranged ? pre->chunks * chunk_split : (capm && i == plan.passes - 1) ? 1 : seg_blocks(ctx, n_seg);
       blocks = n_seg * bseg;
       src.tuples = in_tuples;
       src.seg_off = seg_in;
@@ -811,7 +830,7 @@ int olap_join_presplit_u32(olap_ctx* ctx, const uint64_t* left_tuples, uint64_t 
 static int partition_run(olap_ctx* ctx, const uint32_t* const* key_ptrs, const uint32_t* const* payload_ptrs,
                          const uint64_t* rows, uint64_t n_batches, int in_mem, uint32_t nr_partitions,
                          uint32_t* out_keys, uint32_t* out_payload, uint2* out_tuples, uint64_t out_capacity,
-                         int out_mem, uint64_t* out_offsets) {
+                         int out_mem, uint64_t* out_offsets, const BucketOrder* order = nullptr) {
   if (!ctx) return OLAP_ERR_INVALID;
   if (hipSetDevice(ctx->device) != hipSuccess) return ctx->fail(OLAP_ERR_DEVICE, "hipSetDevice failed");
   if ((in_mem != OLAP_MEM_HOST && in_mem != OLAP_MEM_DEVICE) || (out_mem != OLAP_MEM_HOST && out_mem != OLAP_MEM_DEVICE))
@@ -850,7 +869,7 @@ static int partition_run(olap_ctx* ctx, const uint32_t* const* key_ptrs, const u
     return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (partition buffers)");
   SideOut pso;
   OLAP_TRY(partition_side(ctx, cs, payload_ptrs != nullptr, nullptr, 0, plan, (uint32_t)ctx->hash_skip_bits, tmp0, tmp1,
-                          fin, false, nullptr, &pso));
+                          fin, false, nullptr, &pso, nullptr, false, order));
   if (N && !zipped) {
     PhaseScope ps(ctx, PH_PART_SCATTER);
     uint64_t grid = (N + 255) / 256;
@@ -888,6 +907,30 @@ int olap_partition_tuples_u32(olap_ctx* ctx, const uint32_t* const* key_ptrs, co
   }
   return partition_run(ctx, key_ptrs, payload_ptrs, rows, n_batches, in_mem, nr_partitions, nullptr, nullptr,
                        reinterpret_cast<uint2*>(out_tuples), out_capacity, OLAP_MEM_DEVICE, out_offsets);
+}
+
+int olap_split_tuples_u32(olap_ctx* ctx, const uint32_t* const* key_ptrs, const uint32_t* const* payload_ptrs,
+                          const uint64_t* rows, uint64_t n_batches, int in_mem, uint32_t owner_bits, uint32_t group_bits,
+                          uint32_t low_bits, uint64_t* out_tuples, uint64_t out_capacity, uint64_t* out_offsets) {
+  if (!ctx) return OLAP_ERR_INVALID;
+  const uint32_t bits = owner_bits + group_bits + low_bits;
+  if (bits < 1 || bits > (uint32_t)kMaxFBits || owner_bits > 10 || group_bits > 10 || low_bits > 10)
+    return ctx->fail(OLAP_ERR_INVALID, "owner + group + low bits must be in [1, %d] (one radix pass)", kMaxFBits);
+  if (ctx->max_bits_per_pass > 0 && bits > (uint32_t)ctx->max_bits_per_pass)
+    return ctx->fail(OLAP_ERR_INVALID, "the split needs one pass of %u bits but max_bits_per_pass is %d", bits, ctx->max_bits_per_pass);
+  if (!out_tuples) {
+    uint64_t n = 0;
+    for (uint64_t b = 0; rows && b < n_batches; ++b) n += rows[b];
+    if (n) return ctx->fail(OLAP_ERR_INVALID, "out_tuples is null");
+    static uint64_t dummy[2] __attribute__((aligned(16)));
+    out_tuples = dummy;  // nothing is written for an empty input
+  }
+  BucketOrder order;
+  order.owner_bits = owner_bits;
+  order.group_bits = group_bits;
+  order.low_bits = low_bits;
+  return partition_run(ctx, key_ptrs, payload_ptrs, rows, n_batches, in_mem, 1u << bits, nullptr, nullptr,
+                       reinterpret_cast<uint2*>(out_tuples), out_capacity, OLAP_MEM_DEVICE, out_offsets, &order);
 }
 
 }  // extern "C"

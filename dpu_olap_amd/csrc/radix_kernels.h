@@ -46,6 +46,7 @@ struct PassSrc {
   // SRC_TUPLES, pre-split input: block k of the grid reads tuples [blk_range[2k], blk_range[2k+1])
   // (one chunk per sender of an exchanged segment) instead of an even share of its segment
   const uint64_t* blk_range;
+  uint32_t chunk_split;  // workgroups per chunk (>= 1): workgroup k reads share k % chunk_split of chunk k / chunk_split
   // SRC_TUPLES, input written by the claiming scatter (k_part_scatter_claim): segment k is
   // [k * seg_cap, k * seg_cap + min(seg_cnt[k], seg_cap)) and holds filler tuples, which are
   // recognised by their hash: a real tuple of segment k has ((hash >> chk_shift) & chk_mask)
@@ -54,7 +55,25 @@ struct PassSrc {
   uint32_t seg_cap;
   uint32_t chk_shift;
   uint32_t chk_mask;  // 0: every tuple in range is real
+  // Bucket ORDER of a single-pass split (olap_split_tuples_u32): the bucket id read from the hash is
+  // [owner | group | low] (ord_owner_bits, ord_group_bits, ord_low_bits wide); it is emitted as
+  // [group | owner | low], so that everything a sub-bucket group sends to all owners is one contiguous run.
+  uint32_t ord_owner_bits;
+  uint32_t ord_group_bits;  // 0: natural order
+  uint32_t ord_low_bits;
 };
+
+// Bucket of a tuple in a pass: the bits [shift, shift + log2 F) of its hash, in the pass's bucket order.
+__device__ __forceinline__ uint32_t pass_bucket(const PassSrc& s, uint32_t h, uint32_t shift, uint32_t F) {
+  uint32_t b = (h >> shift) & (F - 1);
+  if (s.ord_group_bits) {
+    const uint32_t low = b & ((1u << s.ord_low_bits) - 1u);
+    const uint32_t grp = (b >> s.ord_low_bits) & ((1u << s.ord_group_bits) - 1u);
+    const uint32_t own = b >> (s.ord_low_bits + s.ord_group_bits);
+    b = (grp << (s.ord_owner_bits + s.ord_low_bits)) | (own << s.ord_low_bits) | low;
+  }
+  return b;
+}
 
 struct TileRange {
   uint64_t t0, t1;    // tile ids
@@ -75,11 +94,14 @@ __device__ __forceinline__ TileRange block_tiles(const PassSrc& s) {
   } else {
     r.seg = blockIdx.x / s.blocks_per_seg;
     if (s.blk_range) {
-      r.lo = s.blk_range[2 * (uint64_t)blockIdx.x];
-      r.hi = s.blk_range[2 * (uint64_t)blockIdx.x + 1];
+      const uint32_t split = s.chunk_split ? s.chunk_split : 1u;
+      const uint64_t chunk = blockIdx.x / split, part = blockIdx.x - chunk * split;
+      r.lo = s.blk_range[2 * chunk];
+      r.hi = s.blk_range[2 * chunk + 1];
       r.a = r.lo & ~1ull;
-      r.t0 = 0;
-      r.t1 = (r.hi - r.a + TILE - 1) / TILE;
+      const uint64_t tiles = (r.hi - r.a + TILE - 1) / TILE, q = (tiles + split - 1) / split;
+      r.t0 = min(part * q, tiles);
+      r.t1 = min(r.t0 + q, tiles);
       return r;
     }
     const uint32_t j = blockIdx.x - r.seg * s.blocks_per_seg;
@@ -240,7 +262,7 @@ __global__ __launch_bounds__(BLOCK) void k_part_hist(PassSrc s, uint32_t shift, 
     const uint32_t mask = load_tile<SRC, BLOCK, false, TILE>(s, r, tile, cur, key, pay);
 #pragma unroll
     for (int i = 0; i < TPT; ++i) {
-      if (mask & (1u << i)) atomicAdd(&cl[(wang_hash(key[i]) >> shift) & (F - 1)], 1u);
+      if (mask & (1u << i)) atomicAdd(&cl[pass_bucket(s, wang_hash(key[i]), shift, F)], 1u);
     }
   }
   __syncthreads();
@@ -324,7 +346,7 @@ __global__ __launch_bounds__(kPBlock, 4) void k_part_scatter(PassSrc s, uint32_t
     for (int i = 0; i < kTPT; ++i) {
       br[i] = 0;
       if (mask & (1u << i)) {
-        const uint32_t b = (wang_hash(key[i]) >> shift) & (F - 1);
+        const uint32_t b = pass_bucket(s, wang_hash(key[i]), shift, F);
         br[i] = (b << 16) | atomicAdd(&cl[b], 1u);
       }
     }
@@ -371,7 +393,7 @@ __global__ __launch_bounds__(kPBlock, 4) void k_part_scatter(PassSrc s, uint32_t
 #pragma unroll 4
     for (uint32_t i = threadIdx.x; i < n_tile; i += kPBlock) {
       const uint2 t = stage[i];
-      const uint32_t b = (wang_hash(t.x) >> shift) & (F - 1);
+      const uint32_t b = pass_bucket(s, wang_hash(t.x), shift, F);
       out[gcur[b] + (i - cl[b])] = t;
     }
     __syncthreads();
@@ -486,7 +508,7 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_wc(PassSrc s, uint32_t s
     if (mask == kFull && !s.chk_mask) {  // whole tile valid (all but the edge tiles): no per-tuple predication
 #pragma unroll
       for (int i = 0; i < kWTPT; ++i) {
-        const uint32_t b = (wang_hash(key[i]) >> shift) & (F - 1);
+        const uint32_t b = pass_bucket(s, wang_hash(key[i]), shift, F);
         br[i] = (b << 16) | atomicAdd(&cl[b], 1u);
       }
     } else {
@@ -497,7 +519,7 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_wc(PassSrc s, uint32_t s
         const uint32_t h = wang_hash(key[i]);
         if (((h >> s.chk_shift) & s.chk_mask) != expect) mask &= ~(1u << i);  // a filler of the claiming scatter
         if (mask & (1u << i)) {
-          const uint32_t b = (h >> shift) & (F - 1);
+          const uint32_t b = pass_bucket(s, h, shift, F);
           br[i] = (b << 16) | atomicAdd(&cl[b], 1u);
         }
       }
@@ -693,7 +715,7 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_claim(PassSrc s, uint32_
       const uint32_t h = wang_hash(key[i]);
       if (((h >> s.chk_shift) & s.chk_mask) != expect) mask &= ~(1u << i);
       if (mask & (1u << i)) {
-        const uint32_t b = (h >> shift) & (F - 1);
+        const uint32_t b = pass_bucket(s, h, shift, F);
         br[i] = (b << 16) | atomicAdd(&cl[b], 1u);
       }
     }
@@ -800,7 +822,7 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_claim(PassSrc s, uint32_
     uint32_t pos = m.y, rem = m.w & 0xFFFFu;
     const uint32_t rr = (m.w >> 16) & 15u;
     uint32_t filler = 0;
-    while (((wang_hash(filler) >> shift) & (F - 1)) == b_own) ++filler;  // a key of another bucket
+    while (pass_bucket(s, wang_hash(filler), shift, F) == b_own) ++filler;  // a key of another bucket
     uint2* region = out + p_own * co.cap;
     bool ok = true;
     if (rr && rem == 0) {

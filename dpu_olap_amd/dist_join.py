@@ -43,6 +43,8 @@ class GpuLocalOps:
     overlap_right_exchange = True   # fused path: the left table's radix pass runs under the right table's exchange
     left_slices = 2                 # fused path: the left table is split and shipped in this many input slices, so the
                                     # links start working after 1/left_slices of the split instead of all of it
+    exchange_groups = 4             # fused path: a table travels as this many sub-bucket groups; group g is joined
+                                    # while group g + 1 is on the links
 
     def __init__(self, ctx: capi.Context, device: torch.device):
         self.ctx = ctx
@@ -73,6 +75,21 @@ class GpuLocalOps:
                                              capi.MEM_DEVICE, nr_partitions, out.data_ptr(), n)
         return out, offs
 
+    def split_tuples(self, keys: Sequence[torch.Tensor], payload: Sequence[torch.Tensor], owner_bits: int, group_bits: int,
+                     low_bits: int):
+        """The multi-GPU split (olap_split_tuples_u32): buckets [owner | group | low], laid out group-major."""
+        rows = [int(k.numel()) for k in keys]
+        n = sum(rows)
+        out = self.empty_tuples(n)
+        torch.cuda.current_stream(self.device).synchronize()  # inputs come from torch's stream; do not wait for RCCL's
+        offs = self.ctx.split_tuples_u32([k.data_ptr() for k in keys], [p.data_ptr() for p in payload], rows, capi.MEM_DEVICE,
+                                         owner_bits, group_bits, low_bits, out.data_ptr(), n)
+        return out, offs
+
+    def empty_result(self, n: int):
+        """The three result columns of this rank, filled group by group."""
+        return tuple(self.empty(n) for _ in range(3))
+
     def join_tuples(self, lt: torch.Tensor, rt: torch.Tensor, skip_bits: int = 0):
         n = int(lt.numel())
         out = [self.empty(n) for _ in range(3)]
@@ -86,14 +103,14 @@ class GpuLocalOps:
         return out[0][:got], out[1][:got], out[2][:got], stats
 
     def join_presplit(self, lt: torch.Tensor, l_lo, l_hi, rt: torch.Tensor, r_lo, r_hi, n_segments: int, chunks: int,
-                      skip_bits: int = 0, right_ready: "torch.cuda.Event | None" = None):
+                      skip_bits: int = 0, right_ready: "torch.cuda.Event | None" = None, out=None):
         """Local join of exchanged tuples that are still grouped (sender, sub-bucket): the first
         radix pass reads the chunks in place (olap_join_presplit_u32).  right_ready: an event
         recorded behind the right table's exchange -- the left table's pass then runs while the
         right table is still arriving."""
         l_ptr, l_span, l_lo, l_hi, n = self._span(lt, l_lo, l_hi)
         r_ptr, r_span, r_lo, r_hi, _ = self._span(rt, r_lo, r_hi)
-        out = [self.empty(n) for _ in range(3)]
+        out = list(out) if out is not None else [self.empty(n) for _ in range(3)]   # out: slices of empty_result()
         if right_ready is None:
             torch.cuda.current_stream(self.device).synchronize()  # inputs come from torch's stream; do not wait for RCCL's
         else:
@@ -224,33 +241,48 @@ def _chunk_tables(cnt: torch.Tensor):
     return [int(v) for v in lo], [int(v) for v in hi]
 
 
-def _spread(lo, hi, S: int, world: int, H: int):
-    """Re-index a (segment, sender) chunk table as (segment, H x world) with empty chunks in the extra places."""
-    if H == 1:
-        return lo, hi
-    nlo, nhi = [0] * (S * H * world), [0] * (S * H * world)
-    for j in range(S):
-        for q in range(world):
-            nlo[j * H * world + q], nhi[j * H * world + q] = lo[j * world + q], hi[j * world + q]
-        for k in range(world, H * world):
-            nlo[j * H * world + k] = nhi[j * H * world + k] = hi[j * world + world - 1]
-    return nlo, nhi
+class _Shipped:
+    """One input slice of one table after the split, its K group exchanges in flight:
+    pend[g].wait() -> what this rank received for sub-bucket group g (sender-major, then low sub-bucket);
+    recv[q][g][l] = tuples sender q shipped for (group g, low sub-bucket l); sent[g][p], got[g][q] = message sizes."""
+
+    def __init__(self, pend, recv, sent, got):
+        self.pend, self.recv, self.sent, self.got = pend, recv, sent, got
 
 
-def _fused_side(ops, keys, payload, world: int, S: int, group, async_op: bool):
-    """Split one table into world x S buckets (owner = top bits, sub-bucket = next bits), ship
-    every owner its S runs as one message, and return (pending tuples, chunk lo, chunk hi,
-    rows sent, rows received)."""
-    t, off = ops.partition_tuples(keys, payload, world * S)
-    cnt_in = torch.tensor([off[k + 1] - off[k] for k in range(world * S)], dtype=torch.int64, device=t.device)
-    cnt_out = _exchange_counts(cnt_in, world, group).view(world, S).cpu()
-    in_splits = [int(v) for v in cnt_in.view(world, S).sum(1).cpu()]
-    out_splits = [int(v) for v in cnt_out.sum(1)]
-    pend = _exchange(t, in_splits, out_splits, ops.empty_tuples, group, async_op=True)
-    if not async_op:
-        pend = _Pending(pend.wait())
-    lo, hi = _chunk_tables(cnt_out)
-    return pend, lo, hi, in_splits, out_splits
+def _split_and_ship(ops, keys, payload, world: int, gbits: int, lbits: int, group) -> _Shipped:
+    """Split one slice into world x K x L buckets (owner = top hash bits, then group, then low sub-bucket)
+    laid out group-major, and start one all-to-all per group."""
+    obits, K, L = world.bit_length() - 1, 1 << gbits, 1 << lbits
+    t, off = ops.split_tuples(keys, payload, obits, gbits, lbits)          # bucket order (group, owner, low)
+    cnt = torch.tensor([off[k + 1] - off[k] for k in range(K * world * L)], dtype=torch.int64).view(K, world, L)
+    to_peers = cnt.permute(1, 0, 2).contiguous().view(-1)                 # per owner: its K x L counts
+    dev = t.device
+    recv = _exchange_counts(to_peers.to(dev), world, group).view(world, K, L).cpu()
+    sent = [[int(v) for v in cnt[g].sum(1)] for g in range(K)]
+    got = [[int(v) for v in recv[:, g].sum(1)] for g in range(K)]
+    pend = []
+    for g in range(K):
+        run = t[off[g * world * L]:off[(g + 1) * world * L]]               # everything group g sends, owner-major
+        pend.append(_exchange(run, sent[g], got[g], ops.empty_tuples, group, async_op=True))
+    return _Shipped(pend, recv, sent, got)
+
+
+def _group_tables(slices, g: int, world: int, L: int, width: int):
+    """Chunk tables of group g for one table shipped in len(slices) input slices: segment l has `width`
+    chunk places; place (h, q) holds what sender q shipped in slice h, the rest stay empty.  Chunk indices
+    count through the concatenation of the slices' receive buffers."""
+    lo, hi, v = [0] * (L * width), [0] * (L * width), 0
+    for h, sh in enumerate(slices):
+        c_lo, c_hi = _chunk_tables(sh.recv[:, g])
+        for l in range(L):
+            for q in range(world):
+                lo[l * width + h * world + q], hi[l * width + h * world + q] = v + c_lo[l * world + q], v + c_hi[l * world + q]
+        v += sum(sh.got[g])
+    for l in range(L):                                                     # empty places repeat the previous end (lo == hi)
+        for k in range(len(slices) * world, width):
+            lo[l * width + k] = hi[l * width + k] = hi[l * width + len(slices) * world - 1]
+    return lo, hi
 
 
 def distributed_join(ops, left_batches: Sequence, right_batches: Sequence, group=None, timers: dict | None = None):
@@ -267,49 +299,74 @@ def distributed_join(ops, left_batches: Sequence, right_batches: Sequence, group
     g = world.bit_length() - 1
     rank = dist.get_rank(group)
     if hasattr(ops, "join_presplit") and world <= (1 << (FUSED_SPLIT_BITS - 1)) and getattr(ops, "fused", True):
-        # fused path: the owner split IS the first radix pass (world x S = 512 buckets); each
-        # owner receives, per sender, its S sub-bucket runs, and its next pass reads them in
-        # place.  The left table's exchange overlaps the split of the right table.
+        # fused path: the owner split IS the first radix pass (world x K x L = 512 buckets).  A table is
+        # shipped as K sub-bucket groups (one all-to-all each); the receiver joins group g -- its next radix
+        # pass reads the received runs in place -- while group g + 1 is still on the links.  The left table
+        # goes out in H input slices, so the links start after 1/H of its split.
         S = (1 << FUSED_SPLIT_BITS) // world
+        K = max(1, min(int(getattr(ops, "exchange_groups", 1)), S // 2))
+        K = 1 << (K.bit_length() - 1)
+        gbits, lbits = K.bit_length() - 1, (S // K).bit_length() - 1
+        L = 1 << lbits
         t0 = time.perf_counter()
-        # the left table goes out in H input slices: slice h's exchange runs while slice h + 1 is being split
         H = max(1, min(int(getattr(ops, "left_slices", 1)), len(lfk)))
         cuts = [len(lfk) * h // H for h in range(H + 1)]
-        sides = [_fused_side(ops, lfk[cuts[h]:cuts[h + 1]], ly[cuts[h]:cuts[h + 1]], world, S, group, async_op=True) for h in range(H)]
-        l_in = [sum(sd[3][p] for sd in sides) for p in range(world)]
-        l_out = [sum(sd[4][p] for sd in sides) for p in range(world)]
-        # segment j = chunks (slice h, sender q), numbered through the concatenation of the H receive buffers
-        l_lo, l_hi, v = [0] * (S * H * world), [0] * (S * H * world), 0
-        for h, sd in enumerate(sides):
-            for j in range(S):
-                for q in range(world):
-                    k = j * (H * world) + h * world + q
-                    l_lo[k], l_hi[k] = v + sd[1][j * world + q], v + sd[2][j * world + q]
-            v += sum(sd[4])
-        t1 = time.perf_counter()   # left split + counts done, left tuples in flight
+        left = [_split_and_ship(ops, lfk[cuts[h]:cuts[h + 1]], ly[cuts[h]:cuts[h + 1]], world, gbits, lbits, group) for h in range(H)]
+        t1 = time.perf_counter()   # left table split, its exchanges in flight
+        right = _split_and_ship(ops, rpk, rx, world, gbits, lbits, group)
+        t2 = time.perf_counter()   # right table split, all exchanges issued
         overlap = getattr(ops, "overlap_right_exchange", False)
-        pend_r, r_lo, r_hi, r_in, r_out = _fused_side(ops, rpk, rx, world, S, group, async_op=overlap)
-        RL = [sd[0].wait() for sd in sides]
-        if RL[0].is_cuda:
-            torch.cuda.current_stream(RL[0].device).synchronize()   # the left table has arrived
-        ready = None
-        RR = pend_r.wait()          # RCCL: orders torch's stream behind the transfer, does not block the host
-        if overlap and RR.is_cuda:
-            ready = torch.cuda.Event()
-            ready.record(torch.cuda.current_stream(RR.device))
-        t2 = time.perf_counter()   # right split done; exchanges done (or, overlapped, the right one still in flight)
-        r_lo, r_hi = _spread(r_lo, r_hi, S, world, H)   # both sides use H x world chunks per segment (the right one: empty extras)
-        RLx = RL if H > 1 else RL[0]
-        fk, y, x, stats = (ops.join_presplit(RLx, l_lo, l_hi, RR, r_lo, r_hi, S, H * world, g, right_ready=ready) if ready is not None
-                           else ops.join_presplit(RLx, l_lo, l_hi, RR, r_lo, r_hi, S, H * world, g))
+        n_left = [sum(sum(sh.got[gi]) for sh in left) for gi in range(K)]          # left rows this rank joins, per group
+        out = ops.empty_result(sum(n_left)) if hasattr(ops, "empty_result") else None
+        pieces, stats, row0 = [], None, 0
+        width = H * world
+        for gi in range(K):
+            RL = [sh.pend[gi].wait() for sh in left]
+            if RL[0].is_cuda:
+                torch.cuda.current_stream(RL[0].device).synchronize()            # group gi of the left table has arrived
+            RR = right.pend[gi].wait()   # RCCL: orders torch's stream behind the transfer, does not block the host
+            ready = None
+            if overlap and RR.is_cuda:
+                ready = torch.cuda.Event()
+                ready.record(torch.cuda.current_stream(RR.device))
+            elif RR.is_cuda:
+                torch.cuda.current_stream(RR.device).synchronize()
+            l_lo, l_hi = _group_tables(left, gi, world, L, width)
+            r_lo, r_hi = _group_tables([right], gi, world, L, width)
+            kw = {}
+            if ready is not None:
+                kw["right_ready"] = ready
+            if out is not None:
+                kw["out"] = tuple(c[row0:row0 + n_left[gi]] for c in out)
+            fk, y, x, st = ops.join_presplit(RL if H > 1 else RL[0], l_lo, l_hi, RR, r_lo, r_hi, L, width, g + gbits, **kw)
+            pieces.append((fk, y, x))
+            row0 += n_left[gi]
+            if stats is None:
+                stats = dict(st)
+            else:
+                for key in ("left_rows", "right_rows", "missing_keys", "duplicate_keys"):
+                    if key in st:
+                        stats[key] = stats.get(key, 0) + st[key]
+                if "max_build_rows" in st:
+                    stats["max_build_rows"] = max(stats.get("max_build_rows", 0), st["max_build_rows"])
+                if "nr_partitions" in st:
+                    stats["nr_partitions"] = stats.get("nr_partitions", 0) + st["nr_partitions"]
         t3 = time.perf_counter()
+        if out is not None:
+            got = sum(int(p[0].numel()) for p in pieces)
+            fk, y, x = (c[:got] for c in out) if got == sum(n_left) else (torch.cat([p[i] for p in pieces]) for i in range(3))
+        else:
+            fk, y, x = (torch.cat([p[i] for p in pieces]) for i in range(3))
+        l_in = [sum(sh.sent[gi][p] for sh in left for gi in range(K)) for p in range(world)]
+        r_in = [sum(right.sent[gi][p] for gi in range(K)) for p in range(world)]
+        recv_left, recv_right = sum(n_left), sum(sum(right.got[gi]) for gi in range(K))
         sent = sum(l_in) + sum(r_in) - l_in[rank] - r_in[rank]
-        wall = {"split_left+counts": (t1 - t0) * 1e3, "split_right+exchanges": (t2 - t1) * 1e3, "local_join": (t3 - t2) * 1e3}
+        wall = {"split_left+counts": (t1 - t0) * 1e3, "split_right+counts": (t2 - t1) * 1e3, "exchanges+group_joins": (t3 - t2) * 1e3}
         if timers is not None:
-            for k, v in wall.items():
-                timers[k] = timers.get(k, 0.0) + v
-        return fk, y, x, {"world": world, "stats": stats, "sent_rows": sent, "recv_left": sum(l_out),
-                          "recv_right": sum(r_out), "path": "fused", "wall_ms": wall}
+            for key, v in wall.items():
+                timers[key] = timers.get(key, 0.0) + v
+        return fk, y, x, {"world": world, "stats": stats, "sent_rows": sent, "recv_left": recv_left, "recv_right": recv_right,
+                          "path": "fused", "groups": K, "left_slices": H, "wall_ms": wall}
     if hasattr(ops, "partition_tuples"):
         # zipped path: one int64 tensor per table; the left table's exchange overlaps the
         # owner split of the right table (RCCL runs on its own stream)

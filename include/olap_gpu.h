@@ -205,6 +205,20 @@ int olap_join_tuples_u32(olap_ctx* ctx, const uint64_t* left_tuples, uint64_t n_
                          uint32_t* out_y, uint32_t* out_x, uint64_t out_capacity, uint64_t* out_rows,
                          olap_join_stats* stats /* may be NULL */);
 
+/* The multi-device split: olap_partition_tuples_u32 with 2^(owner_bits + group_bits + low_bits)
+ * buckets in ONE radix pass, but with the buckets laid out group-major.  A tuple's bucket id, read
+ * from the top bits of its hash below the skipped ones, is [owner | group | low]; the output (and
+ * out_offsets, 2^bits + 1 entries) is ordered [group | owner | low].  So what a rank sends to
+ * all owners for one sub-bucket GROUP is a single contiguous run -- one all_to_all_single per
+ * group -- and a receiver can join group g (olap_join_presplit_u32 with
+ * olap_join_set_hash_skip_bits(owner_bits + group_bits) and 2^low_bits segments) while group
+ * g + 1 is still on the links.  group_bits = 0 gives the natural order. */
+int olap_split_tuples_u32(olap_ctx* ctx, const uint32_t* const* key_ptrs,
+                          const uint32_t* const* payload_ptrs, const uint64_t* rows,
+                          uint64_t n_batches, int in_mem, uint32_t owner_bits, uint32_t group_bits,
+                          uint32_t low_bits, uint64_t* out_tuples, uint64_t out_capacity,
+                          uint64_t* out_offsets);
+
 /* The join on zipped tuples that arrive PRE-SPLIT by their leading hash bits -- what a rank
  * holds when every sender ran olap_partition_tuples_u32 with nr_partitions = ranks x
  * n_segments and shipped each owner its n_segments runs in one message.  Segment j fixes

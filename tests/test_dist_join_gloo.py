@@ -61,37 +61,62 @@ class OracleTupleOps(OracleLocalOps):
 
 
 class OracleFusedOps(OracleTupleOps):
-    """Adds the pre-split join, so distributed_join takes its fused path (owner split = first
-    radix pass).  Checks the chunk tables it is handed: chunk (j, q) must hold only keys
-    whose hash has owner bits = this rank and sub-bucket bits = j."""
+    """Adds the grouped split and the pre-split join, so distributed_join takes its fused path (owner
+    split = first radix pass, tables shipped as sub-bucket groups, one join per group).  Checks what it
+    is handed: every key of a call shares the leading skip bits (owner = this rank, then the group), and
+    chunk (j, c) holds only keys whose next bits are j."""
 
-    left_slices = 2   # like GpuLocalOps: the left table is shipped in two input slices
+    left_slices = 2      # like GpuLocalOps: the left table is shipped in two input slices
+    exchange_groups = 2  # and every table as sub-bucket groups that are joined one by one
 
+    def split_tuples(self, keys, payload, owner_bits, group_bits, low_bits):
+        bits = owner_bits + group_bits + low_bits
+        t, off = self.partition_tuples(keys, payload, 1 << bits)             # natural order [owner | group | low]
+        z = t.numpy()
+        parts, sizes = [], []
+        for g in range(1 << group_bits):                                     # emitted as [group | owner | low]
+            for o in range(1 << owner_bits):
+                for l in range(1 << low_bits):
+                    b = (o << (group_bits + low_bits)) | (g << low_bits) | l
+                    parts.append(z[off[b]:off[b + 1]])
+                    sizes.append(off[b + 1] - off[b])
+        out = torch.from_numpy(np.concatenate(parts).copy()) if parts else t
+        offs = [0]
+        for sz in sizes:
+            offs.append(offs[-1] + sz)
+        return out, offs
 
-    def join_presplit(self, lt, l_lo, l_hi, rt, r_lo, r_hi, n_segments, chunks, skip_bits=0):
-        rank = dist.get_rank()
-        sbits = n_segments.bit_length() - 1
+    def join_presplit(self, lt, l_lo, l_hi, rt, r_lo, r_hi, n_segments, chunks, skip_bits=0, **_kw):
+        rank, world = dist.get_rank(), dist.get_world_size()
+        obits, sbits = world.bit_length() - 1, n_segments.bit_length() - 1
+        lead = set()
 
         def gather(t, lo, hi):
             if isinstance(t, (list, tuple)):       # several receive buffers: chunk indices count through their concatenation
                 t = torch.cat(list(t)) if len(t) else torch.empty(0, dtype=torch.int64)
             z = t.contiguous().numpy().view(np.uint64)
             assert len(lo) == len(hi) == n_segments * chunks
-            assert sum(h - l for l, h in zip(lo, hi)) == z.size, "chunks must tile the received buffer"
+            assert sum(h - l for l, h in zip(lo, hi)) == z.size, "chunks must tile the received buffers"
             parts = []
             for j in range(n_segments):
                 for c in range(chunks):
                     ch = z[lo[j * chunks + c]:hi[j * chunks + c]]
                     h = oracle.wang_hash_np((ch & np.uint64(0xFFFFFFFF)).astype(np.uint32))
-                    if skip_bits:
-                        assert ((h >> np.uint32(32 - skip_bits)) == rank).all()
-                    if sbits:
-                        sub = (h << np.uint32(skip_bits)) >> np.uint32(32 - sbits) if skip_bits else h >> np.uint32(32 - sbits)
-                        assert (sub == j).all(), "chunk holds keys of another sub-bucket"
+                    if ch.size:
+                        assert ((h >> np.uint32(32 - obits)) == rank).all(), "a rank received keys it does not own"
+                        lead.update(np.unique(h >> np.uint32(32 - skip_bits)).tolist())
+                        if sbits:
+                            sub = (h << np.uint32(skip_bits)) >> np.uint32(32 - sbits)
+                            assert (sub == j).all(), "chunk holds keys of another sub-bucket"
                     parts.append(ch)
-            return torch.from_numpy(np.concatenate(parts).view(np.int64).copy()) if parts else t
+            return torch.from_numpy(np.concatenate(parts).view(np.int64).copy()) if parts else torch.empty(0, dtype=torch.int64)
 
-        fk, y, x, st = self.join_tuples(gather(lt, l_lo, l_hi), gather(rt, r_lo, r_hi), skip_bits)
+        L, R = gather(lt, l_lo, l_hi), gather(rt, r_lo, r_hi)
+        assert len(lead) <= 1, "one call = one (owner, group): all keys share the skipped hash bits"
+        if L.numel() == 0:
+            e = torch.empty(0, dtype=torch.int32)
+            return e, e, e, {"skip_bits": skip_bits, "presplit": (n_segments, chunks)}
+        fk, y, x, st = self.join_tuples(L, R, skip_bits)
         st["presplit"] = (n_segments, chunks)
         return fk, y, x, st
 
@@ -119,7 +144,8 @@ def _worker(rank, world, port, case, outdir, tuple_path):
         ops = {"fused": OracleFusedOps, "tuple": OracleTupleOps, "cols": OracleLocalOps}[tuple_path]()
         ofk, oy, ox, info = distributed_join(ops, left, right)
         if tuple_path == "fused":
-            assert info["path"] == "fused" and info["stats"]["presplit"] == (512 // world, 2 * world)
+            assert info["path"] == "fused" and info["groups"] == 2 and info["left_slices"] == 2
+            assert info["stats"]["presplit"] == (512 // world // 2, 2 * world)
         u = lambda tt: tt.contiguous().numpy().view(np.uint32)
         np.savez(os.path.join(outdir, f"rank{rank}.npz"), fk=u(ofk), y=u(oy), x=u(ox),
                  sent=np.array([info["sent_rows"]]), skip=np.array([info["stats"]["skip_bits"]]))
@@ -140,7 +166,7 @@ def test_distributed_join_gloo(tmp_path, world, case, tuple_path):
     for r, s in enumerate(shards):
         owner = oracle.wang_hash_np(s["fk"]) >> np.uint32(32 - bits)
         assert (owner == r).all(), "a rank received keys it does not own"
-        assert int(s["skip"][0]) == bits
+        assert int(s["skip"][0]) in (bits, bits + 1)   # fused path: owner bits + one group bit
         total_sent += int(s["sent"][0])
     fk = np.concatenate([s["fk"] for s in shards])
     y = np.concatenate([s["y"] for s in shards])

@@ -1041,3 +1041,33 @@ def test_c_abi_rejects_misuse_with_status_codes(dev):
     # the context still works
     counts, total = dev.filter_lt(capi.U32, [d.ptr], [1000], capi.MEM_DEVICE, 10, [out.ptr], capi.MEM_DEVICE)
     assert total == 10 and int(counts[0]) == 10
+
+
+@pytest.mark.parametrize("obits,gbits,lbits", [(1, 2, 6), (3, 2, 4), (2, 0, 7), (0, 3, 3)])
+def test_split_tuples_grouped_bucket_order(dev, obits, gbits, lbits):
+    """olap_split_tuples_u32: the same buckets as olap_partition_tuples_u32 with 2^(o+g+l) partitions
+    (the top hash bits), laid out [group | owner | low] instead of [owner | group | low]."""
+    import torch
+    from dpu_olap_amd.dist_join import GpuLocalOps
+    device = torch.device("cuda", 0)
+    ops = GpuLocalOps(dev, device)
+    rng = np.random.default_rng(obits * 100 + gbits * 10 + lbits)
+    sizes = [70001, 0, 12345, 300000]
+    keys = [torch.from_numpy(rng.integers(0, 1 << 32, size=n, dtype=np.uint32).view(np.int32)).to(device) for n in sizes]
+    pay = [torch.from_numpy(rng.integers(0, 1 << 32, size=n, dtype=np.uint32).view(np.int32)).to(device) for n in sizes]
+    bits = obits + gbits + lbits
+    nat, noff = ops.partition_tuples(keys, pay, 1 << bits)
+    grp, goff = ops.split_tuples(keys, pay, obits, gbits, lbits)
+    nat, grp = nat.cpu().numpy().view(np.uint64), grp.cpu().numpy().view(np.uint64)
+    assert goff[-1] == noff[-1] == sum(sizes)
+    k = 0
+    for g in range(1 << gbits):
+        for o in range(1 << obits):
+            for l in range(1 << lbits):
+                b = (o << (gbits + lbits)) | (g << lbits) | l
+                a = np.sort(grp[goff[k]:goff[k + 1]])
+                e = np.sort(nat[noff[b]:noff[b + 1]])
+                np.testing.assert_array_equal(a, e)
+                h = oracle.wang_hash_np((a & np.uint64(0xFFFFFFFF)).astype(np.uint32))
+                assert ((h >> np.uint32(32 - bits)) == b).all()
+                k += 1
