@@ -1071,3 +1071,56 @@ def test_split_tuples_grouped_bucket_order(dev, obits, gbits, lbits):
                 h = oracle.wang_hash_np((a & np.uint64(0xFFFFFFFF)).astype(np.uint32))
                 assert ((h >> np.uint32(32 - bits)) == b).all()
                 k += 1
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_scan_ops_random_shapes_vs_oracle(dev, seed):
+    """Seeded random batch shapes (empty, one-row, tile-boundary, ragged, a long batch), the four
+    element types, host or device operands: filter / sum / take / partition against the oracle
+    (numpy for the 64-bit and signed types, whose semantics SURVEY 8 pins to Arrow's)."""
+    o = _ops()
+    rng = np.random.default_rng(500 + seed)
+    dt = [np.uint32, np.int32, np.uint64, np.int64][seed % 4]
+    sizes = [int(x) for x in rng.choice([0, 1, 3, 255, 256, 1023, 4096, 4097, 16383, 65536, 65537, 100003], size=int(rng.integers(1, 8)))]
+    if seed % 5 == 0:
+        sizes[int(rng.integers(len(sizes)))] = int(rng.integers(300_000, 1_500_000))
+    info = np.iinfo(dt)
+    batches = [rng.integers(info.min, info.max, size=n, dtype=dt, endpoint=True) for n in sizes]
+    thr = int(rng.integers(info.min, info.max, dtype=dt, endpoint=True)) if seed % 3 else int(info.min)   # also "nothing passes"
+    space = "device" if seed % 2 else "host"
+    wrap = (lambda a: a) if space == "host" else dev.to_device
+    get = (lambda a: a) if space == "host" else dev.to_host
+    ins = [wrap(b) for b in batches]
+    # filter: order-preserving v < thr in the column's own type
+    res = o.FilterGpu(dev, ins, threshold=thr).Prepare().GetResult()
+    assert len(res) == len(batches)
+    for r, b in zip(res, batches):
+        np.testing.assert_array_equal(get(r), b[b < dt(thr)])
+    # sum: 64-bit accumulator, wraps mod 2^64 (signed: two's complement)
+    want = int(sum(int(b.astype(np.int64 if info.min < 0 else np.uint64).sum(dtype=np.int64 if info.min < 0 else np.uint64)) for b in batches))
+    got = o.SumGpu(dev, ins).Prepare().Run()
+    mod = 1 << 64
+    assert (got - want) % mod == 0
+    # take: per batch, no bounds check needed for in-range indices
+    data = [b for b in batches if b.size]
+    if data:
+        idx = [rng.integers(0, d.size, size=int(rng.choice([0, 1, 7, 4096, 8192, 8193, 50000])), dtype=np.uint32) for d in data]
+        out = o.TakeGpu(dev, [wrap(d) for d in data], [wrap(i) for i in idx]).Prepare().Run()
+        for r, d, i in zip(out, data, idx):
+            np.testing.assert_array_equal(get(r), d[i])
+    # partition (u32 keys): bucket = top bits of the Wang hash; contents per bucket as a set of (key, payload)
+    keys = [rng.integers(0, 1 << 32, size=n, dtype=np.uint32) for n in sizes]
+    pay = [rng.integers(0, 1 << 32, size=n, dtype=np.uint32) for n in sizes]
+    P = int(rng.choice([2, 4, 32, 256, 1024, 4096]))
+    parts = o.PartitionGpu(dev, [(wrap(k), wrap(p)) for k, p in zip(keys, pay)], P).Prepare().Run()
+    allk, allp = np.concatenate(keys), np.concatenate(pay)
+    bucket = oracle.wang_hash_np(allk) >> np.uint32(32 - (P.bit_length() - 1))
+    ok_, _, hist_end = oracle.partition(allk, P)
+    assert [int(h) for h in hist_end] == list(np.cumsum([pk.size for pk, _ in parts]))       # the oracle's END offsets
+    for p in (0, P // 2, P - 1, int(rng.integers(P))):
+        gk, gp = parts[p]
+        sel = bucket == p
+        a = sort_rows(gk, gp)
+        e = sort_rows(allk[sel], allp[sel])
+        np.testing.assert_array_equal(a[0], e[0])
+        np.testing.assert_array_equal(a[1], e[1])
