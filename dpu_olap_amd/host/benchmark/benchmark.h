@@ -149,3 +149,27 @@ void Shutdown();
           new ::benchmark::internal::Benchmark(#BaseClass "/" #Method, [] {                  \
             return std::unique_ptr<::benchmark::Fixture>(new BaseClass##_##Method##_Benchmark()); \
           }))
+
+// BENCHMARK(func): a plain function void func(benchmark::State&), name = "func" (no fixture prefix).
+namespace benchmark {
+namespace internal {
+class FunctionFixture : public Fixture {
+ public:
+  explicit FunctionFixture(void (*fn)(State&)) : fn_(fn) {}
+
+ protected:
+  void BenchmarkCase(State& state) override { fn_(state); }
+
+ private:
+  void (*fn_)(State&);
+};
+}  // namespace internal
+}  // namespace benchmark
+
+#define BENCHMARK(func)                                                                        \
+  static ::benchmark::internal::Benchmark* BENCHMARK_PRIVATE_CONCAT(benchmark_reg_, __LINE__)   \
+      __attribute__((unused)) = ::benchmark::internal::RegisterBenchmarkInternal(              \
+          new ::benchmark::internal::Benchmark(#func, [] {                                      \
+            return std::unique_ptr<::benchmark::Fixture>(new ::benchmark::internal::FunctionFixture(func)); \
+          }))
+

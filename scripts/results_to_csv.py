@@ -20,7 +20,8 @@ import sys
 
 def name_fields(name: str) -> dict:
     parts = name.split("/")
-    out = {"operator": parts[1] if len(parts) > 1 else parts[0]}
+    # "Fixture/BM_Op/..." for fixture benchmarks, "BM_Op/..." for plain functions
+    out = {"operator": next((p for p in parts if p.startswith("BM_")), parts[1] if len(parts) > 1 else parts[0])}
     for part in parts:
         key, sep, val = part.partition(":")
         if sep:

@@ -41,7 +41,9 @@ def test_native_operators_and_registry(host_build):
                  "BM_TakeGpu/Batches:2/Batch-Size:4194304/Indices-Batch-Size:524288/GPUs:1",
                  "BM_SumGpu/Batches:64/Batch-Size:65536/GPUs:1", "BM_JoinNative/Batches:64/L-Batch-Size:65536/R-Batch-Size:65536/Partitioned:1",
                  "BM_JoinGpu/Batches:2/L-Batch-Size:2097152/R-Batch-Size:2097152/GPUs:1",
-                 "BM_PartitionGpu/Batches:2/Batch-Size:2097152/GPUs:1/Partitions:2"):
+                 "BM_PartitionGpu/Batches:2/Batch-Size:2097152/GPUs:1/Partitions:2",
+                 "BM_JoinGpuResident/Batches:2/L-Batch-Size:2097152/R-Batch-Size:2097152/GPUs:1",
+                 "BM_FilterGpuResident/Batches:256/Batch-Size:65536/GPUs:1"):
         assert frag in names, frag
 
 
@@ -92,8 +94,13 @@ def test_cpp_gpu_benchmarks_run(host_build, tmp_path):
     d = json.load(open(out_json))
     ran = [b for b in d["benchmarks"] if not b.get("error_occurred")]
     names = " ".join(b["name"] for b in ran)
-    for frag in ("BM_FilterGpu", "BM_TakeGpu", "BM_SumGpu", "BM_JoinGpu", "BM_PartitionGpu"):
+    for frag in ("BM_FilterGpu", "BM_TakeGpu", "BM_SumGpu", "BM_JoinGpu", "BM_PartitionGpu", "BM_FilterGpuResident", "BM_SumGpuResident",
+                 "BM_JoinGpuResident"):
         assert frag in names
+    jr = [b for b in ran if b["name"].startswith("BM_JoinGpuResident")][0]      # device-resident: no copies, all rows joined
+    assert jr["iterations"] == 3 and jr["gpu-work"] > 0 and "copy-to-gpu" not in jr
+    fr = [b for b in ran if b["name"].startswith("BM_FilterGpuResident")][0]
+    assert abs(fr["Results (AVG)"] / (256 * 65536) - 0.25) < 0.01
     f = [b for b in ran if "BM_FilterGpu" in b["name"]][0]
     assert abs(f["Results (AVG)"] / f["Processed (AVG)"] - 0.25) < 0.01
     assert f["gpu-work"] > 0 and f["copy-to-gpu"] > 0  # the reference's timer counters, renamed
