@@ -8,7 +8,7 @@
 //   BM_Sum{Native,Gpu}    {SF, 2Mi, ..} and {SF<<5, 64Ki, ..}
 //   BM_JoinNative         {SF<<5, 64Ki, 64Ki, Partitioned 1|0};  BM_JoinGpu {SF, 2Mi, 2Mi, GPUs}
 //   BM_PartitionGpu       {SF, 2Mi, GPUs, Partitions = max(SF, 2)}
-//   BM_{Filter,Sum,Join}GpuResident   the same shapes with the columns generated in HBM (device pointers through the C ABI)
+//   BM_{Filter,Sum,Take,Join}GpuResident   the same shapes with the columns generated in HBM (device pointers through the C ABI)
 // Prepare() runs inside the timed region like in the reference; filter/take/sum force one
 // iteration; {0,...} argument rows free the generated batches between shapes.
 #include <arrow/compute/api.h>
@@ -440,6 +440,35 @@ BENCHMARK(BM_SumGpuResident)
     ->ArgNames({"Batches", "Batch-Size", "GPUs"})
     ->Args({variables::scale_factor(), 2 << 20, variables::max_gpus()})
     ->Args({variables::scale_factor() << 5, 64 << 10, variables::max_gpus()})
+    ->MeasureProcessCPUTime()->UseRealTime()->Unit(benchmark::kMillisecond);
+
+static void BM_TakeGpuResident(benchmark::State& state) {
+  auto dev = DeviceOrSkip(state);
+  if (!dev) return;
+  const int64_t nb = state.range(0), rows = state.range(1), picks = state.range(2);
+  ResidentColumns data(*dev, nb, rows, 1), idx(*dev, nb, picks, 1), out(*dev, nb, picks, 1);
+  olap_ctx* ctx = dev->ctx();
+  // indices uniform in [0, rows): the foreign-key generator with one "left batch" spanning everything
+  if (!data.ok() || !idx.ok() || !out.ok() ||
+      olap_gen_uniform_u32(ctx, (uint32_t*)data.column(0), (uint64_t)data.rows(), kSeed, 1, 0) != OLAP_OK ||
+      olap_gen_fk_u32(ctx, (uint32_t*)idx.column(0), (uint64_t)idx.rows(), kSeed, 2, 0, 1ull << 62, (uint64_t)rows) != OLAP_OK) {
+    state.SkipWithError("device allocation / generation failed");
+    return;
+  }
+  std::vector<void*> outs(nb);
+  for (int64_t b = 0; b < nb; ++b) outs[b] = static_cast<char*>(out.column(0)) + (uint64_t)b * picks * 4;
+  ResidentOp<uint64_t> op(*dev, [&]() -> arrow::Result<uint64_t> {
+    ARROW_RETURN_NOT_OK(dev->Check(olap_take(ctx, OLAP_U32, data.table(0), data.lens(), idx.table32(0), idx.lens(), data.batches(),
+                                             OLAP_MEM_DEVICE, outs.data(), OLAP_MEM_DEVICE)));
+    return (uint64_t)idx.rows();
+  });
+  TimedLoop(state, op, [&](uint64_t) {});
+  CountRows(state, nb * rows);  // items = DATA rows, as take_benchmark.cc:54-56 counts them
+}
+BENCHMARK(BM_TakeGpuResident)
+    ->ArgNames({"Batches", "Batch-Size", "Indices-Batch-Size", "GPUs"})
+    ->Args({variables::scale_factor(), 4 << 20, 512 << 10, variables::max_gpus()})
+    ->Args({variables::scale_factor() << 6, 64 << 10, 8 << 10, variables::max_gpus()})
     ->MeasureProcessCPUTime()->UseRealTime()->Unit(benchmark::kMillisecond);
 
 static void BM_JoinGpuResident(benchmark::State& state) {

@@ -95,7 +95,7 @@ def test_cpp_gpu_benchmarks_run(host_build, tmp_path):
     ran = [b for b in d["benchmarks"] if not b.get("error_occurred")]
     names = " ".join(b["name"] for b in ran)
     for frag in ("BM_FilterGpu", "BM_TakeGpu", "BM_SumGpu", "BM_JoinGpu", "BM_PartitionGpu", "BM_FilterGpuResident", "BM_SumGpuResident",
-                 "BM_JoinGpuResident"):
+                 "BM_TakeGpuResident", "BM_JoinGpuResident"):
         assert frag in names
     jr = [b for b in ran if b["name"].startswith("BM_JoinGpuResident")][0]      # device-resident: no copies, all rows joined
     assert jr["iterations"] == 3 and jr["gpu-work"] > 0 and "copy-to-gpu" not in jr
