@@ -154,9 +154,11 @@ def _worker(rank, world, port, case, outdir, tuple_path):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,tuple_path", [(2, "fused"), (4, "fused"), (2, "tuple"), (2, "cols"), (4, "tuple")])
+@pytest.mark.parametrize("world,tuple_path", [(2, "fused"), (4, "fused"), (8, "fused"), (2, "tuple"), (2, "cols"), (4, "tuple")])
 @pytest.mark.parametrize("case", ["a", "b"])
 def test_distributed_join_gloo(tmp_path, world, case, tuple_path):
+    if world == 8 and case == "a":
+        pytest.skip("the 8-rank run is exercised once (case b)")
     port = _free_port()
     mp.spawn(_worker, args=(world, port, case, str(tmp_path), tuple_path), nprocs=world, join=True)
     g = np.load(os.path.join(GOLDEN_DIR, "arrow_golden.npz"))
