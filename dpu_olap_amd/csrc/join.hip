@@ -521,7 +521,8 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
     if (grid > P) grid = P;
     const PartView rv{Rt, rso.off, rso.cnt, rso.dense, rso.cap};
     const PartView lv{Lt, lso.off, lso.cnt, lso.dense, lso.cap};
-    const uint32_t pair_ok = (uint32_t)(((((uintptr_t)d_fk) | ((uintptr_t)d_y) | ((uintptr_t)d_x)) & 7) == 0);
+    const uintptr_t a_fk = (uintptr_t)d_fk & 7, a_y = (uintptr_t)d_y & 7, a_x = (uintptr_t)d_x & 7;
+    const uint32_t pair_ok = (a_fk | a_y | a_x) == 0 ? 1u : (a_fk == 4 && a_y == 4 && a_x == 4) ? 2u : 0u;
     if (direct) {
       uint64_t dgrid = (uint64_t)ctx->compute_units * 8;
       if (dgrid > P) dgrid = P;

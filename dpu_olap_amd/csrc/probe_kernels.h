@@ -41,7 +41,9 @@ __global__ __launch_bounds__(kJBlock, 4) void k_join_probe(PartView RV, PartView
     const uint64_t n_r = rhi - rlo, n_l = lhi - llo;
     // output rows are dense: tuple at sparse index i goes to row i + delta
     const uint64_t delta = (LV.cap ? LV.dense[p] : llo) - llo;
-    const uint32_t pair_store = pair_store_ok && (delta & 1) == 0;
+    // 8-byte pair stores need an 8-byte aligned element: pair_store_ok 1 = the output columns start 8-byte
+    // aligned, 2 = they all start at 4 mod 8 (a slice of a larger result), 0 = mixed -> 4-byte stores
+    const uint32_t pair_store = pair_store_ok && ((delta + (pair_store_ok >> 1)) & 1) == 0;
     if (n_r > my_max) my_max = n_r;
     if (n_l == 0) continue;
     if (n_r > kTableCap) {
@@ -204,7 +206,9 @@ __global__ __launch_bounds__(kDBlock, 4) void k_join_probe_direct(PartView RV, P
     const uint64_t lhi = LV.cap ? llo + LV.cnt[p] : LV.off[p + 1];
     const uint64_t n_r = rhi - rlo, n_l = lhi - llo;
     const uint64_t delta = (LV.cap ? LV.dense[p] : llo) - llo;
-    const uint32_t pair_store = pair_store_ok && (delta & 1) == 0;
+    // 8-byte pair stores need an 8-byte aligned element: pair_store_ok 1 = the output columns start 8-byte
+    // aligned, 2 = they all start at 4 mod 8 (a slice of a larger result), 0 = mixed -> 4-byte stores
+    const uint32_t pair_store = pair_store_ok && ((delta + (pair_store_ok >> 1)) & 1) == 0;
     if (n_r > my_max) my_max = n_r;
     if (n_l == 0) continue;
     for (uint32_t i = threadIdx.x; i < (slots + 31) / 32; i += kDBlock) s_used[i] = 0;

@@ -1124,3 +1124,23 @@ def test_scan_ops_random_shapes_vs_oracle(dev, seed):
         e = sort_rows(allk[sel], allp[sel])
         np.testing.assert_array_equal(a[0], e[0])
         np.testing.assert_array_equal(a[1], e[1])
+
+
+@pytest.mark.parametrize("shift", [0, 1, 2, 3])
+def test_join_into_misaligned_result_slices(dev, golden, shift):
+    """The result columns may be slices of a larger result (the per-group joins of the multi-GPU path write
+    at arbitrary row offsets): every 4-byte alignment of the output pointers gives the same rows."""
+    fk, y, pk, x = (golden[f"join_b_{k}"] for k in ("fk", "y", "pk", "x"))
+    d = {k: dev.to_device(v) for k, v in (("fk", fk), ("y", y), ("pk", pk), ("x", x))}
+    n = fk.size
+    out = [dev.empty(n + 4, "uint32") for _ in range(3)]
+    offs = [shift, shift, shift] if shift < 3 else [0, 1, 2]          # 3: mixed alignments
+    from dpu_olap_amd import capi
+    rows, st = dev.join_u32([d["fk"].ptr], [d["y"].ptr], [n], [d["pk"].ptr], [d["x"].ptr], [pk.size], capi.MEM_DEVICE,
+                            out[0].ptr + 4 * offs[0], out[1].ptr + 4 * offs[1], out[2].ptr + 4 * offs[2], n, capi.MEM_DEVICE)
+    assert rows == n
+    got = [dev.to_host(o)[k:k + n] for o, k in zip(out, offs)]
+    a, b_, c = sort_rows(*got)
+    np.testing.assert_array_equal(a, golden["join_b_out_fk"])
+    np.testing.assert_array_equal(b_, golden["join_b_out_y"])
+    np.testing.assert_array_equal(c, golden["join_b_out_x"])
