@@ -161,10 +161,11 @@ def load_library(path: str | None = None) -> C.CDLL:
 def _ptr_table(ptrs: Sequence[int]):
     if isinstance(ptrs, C.Array):  # prebuilt table (hot loops over many batches)
         return ptrs
-    arr = (C.c_void_p * max(len(ptrs), 1))()
-    for k, p in enumerate(ptrs):
-        arr[k] = p
-    return arr
+    if not len(ptrs):
+        return (C.c_void_p * 1)()
+    import numpy as np
+    a = np.array([p or 0 for p in ptrs], dtype=np.uint64)      # thousands of batches per call: filled in C
+    return (C.c_void_p * len(ptrs)).from_buffer(a)             # (the ctypes array keeps the numpy buffer alive)
 
 
 def ptr_table(ptrs: Sequence[int]):
@@ -179,11 +180,11 @@ def u64_table(vals: Iterable[int]):
 def _u64_table(vals: Iterable[int]):
     if isinstance(vals, C.Array):
         return vals
-    vals = list(vals)
-    arr = (C.c_uint64 * max(len(vals), 1))()
-    for k, v in enumerate(vals):
-        arr[k] = v
-    return arr
+    import numpy as np
+    a = np.array(list(vals), dtype=np.uint64)
+    if not a.size:
+        return (C.c_uint64 * 1)()
+    return (C.c_uint64 * a.size).from_buffer(a)
 
 
 class Context:
