@@ -252,6 +252,31 @@ TEST(JoinTest, InnerJoinDropsUnmatched) {
     EXPECT_TRUE(native->GetColumnByName(name)->Equals(gpu->GetColumnByName(name)));
 }
 
+TEST(JoinTest, SignedInt32Columns) {
+  // BASELINE's "int32 PK-FK": keys and payloads of Arrow type int32, negative values included -- the join
+  // works on the 32-bit patterns, the result columns keep the input types
+  const int n = 50000;
+  arrow::Int32Builder pkb, xb, fkb, yb;
+  for (int i = 0; i < n; ++i) {
+    EXPECT_TRUE(pkb.Append(i * 7 - 150000).ok());   // negative and positive keys
+    EXPECT_TRUE(xb.Append(-i).ok());
+  }
+  for (int i = 0; i < 2 * n; ++i) {
+    EXPECT_TRUE(fkb.Append(((i * 31) % n) * 7 - 150000).ok());
+    EXPECT_TRUE(yb.Append(i - n).ok());
+  }
+  auto right = RecordBatchOf({"pk", "x"}, {pkb.Finish().ValueOrDie(), xb.Finish().ValueOrDie()});
+  auto left = RecordBatchOf({"fk", "y"}, {fkb.Finish().ValueOrDie(), yb.Finish().ValueOrDie()});
+  auto dev = Gpu();
+  auto native = SortedBy(Go(join::JoinNative{left->schema(), right->schema(), {left}, {right}}).ValueOrDie(), {"fk", "y"});
+  auto got = Go(join::JoinGpu{*dev, left->schema(), right->schema(), {left}, {right}}).ValueOrDie();
+  EXPECT_TRUE(got->field(0)->type()->Equals(arrow::int32()));
+  EXPECT_TRUE(got->field(2)->type()->Equals(arrow::int32()));
+  auto gpu = SortedBy(got, {"fk", "y"});
+  EXPECT_EQ(gpu->num_rows(), 2 * n);
+  for (const auto& name : native->schema()->field_names()) EXPECT_TRUE(native->GetColumnByName(name)->Equals(gpu->GetColumnByName(name)));
+}
+
 TEST(JoinTest, MissingForeignKeyIsAnError) {
   auto left = RecordBatchOf({"fk", "y"}, {ArrayOf<U32>({1, 77}), ArrayOf<U32>({5, 6})});
   auto right = RecordBatchOf({"pk", "x"}, {ArrayOf<U32>({1, 2, 3}), ArrayOf<U32>({7, 8, 9})});
