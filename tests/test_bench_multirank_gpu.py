@@ -50,7 +50,7 @@ def test_bench_ops_two_ranks_on_one_gpu():
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 7                       # 1 filter + 3 sum + 3 take, printed by rank 0 only
+    assert len(lines) == 8                       # 2 filter + 3 sum + 3 take, printed by rank 0 only
     for d in lines:
         assert d["verified"] and d["n_gpus"] == 2 and "GPUs:2" in d["metric"] and d["value"] > 0
     f = lines[0]
@@ -58,4 +58,4 @@ def test_bench_ops_two_ranks_on_one_gpu():
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench_ops.py"), "--sf", "8", "--steps", "1", "--warmup", "0", "--only", "sum"],
                          capture_output=True, text=True, timeout=600, cwd=ROOT)
     single = [json.loads(l) for l in one.stdout.splitlines() if l.startswith("{")]
-    assert [d["result"] for d in single] == [d["result"] for d in lines[1:4]]   # the sharded sums add up to the single-GPU sums
+    assert [d["result"] for d in single] == [d["result"] for d in lines[2:5]]   # the sharded sums add up to the single-GPU sums
