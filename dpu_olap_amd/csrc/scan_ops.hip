@@ -49,10 +49,13 @@ __device__ __forceinline__ int64_t vec_get<int64_t>(const longlong2& v, int k) {
 // ------------------------------------------------------------------ sum
 // One tile = 16 KiB of one batch.  Grid-stride over tiles; per-lane 64-bit
 // accumulator; wave shuffle reduce; LDS across the 4 waves; one atomic per block.
+constexpr int kSumVec = 8;  // 16-B vectors in flight per thread in k_sum (32 KiB tiles)
+
 template <typename T, typename ACC>
 __global__ __launch_bounds__(kBlock) void k_sum(ColView v, const void* const* ptrs,
                                                 unsigned long long* out) {
   constexpr int E = 16 / sizeof(T);
+  constexpr int kVecPerThread = kSumVec;
   constexpr uint32_t TILE = kBlock * kVecPerThread * E;
   using V = typename Vec16<T>::type;
   ACC acc = 0;
@@ -395,7 +398,7 @@ constexpr uint64_t kHostChunkBudget = 1ull << 30;  // staging bytes per round fo
 template <typename T, typename ACC>
 static int run_sum(olap_ctx* ctx, const void* const* ptrs, const uint64_t* rows, uint64_t nb, int in_mem,
                    uint64_t* out_sum) {
-  constexpr uint32_t TILE = kTileBytes / sizeof(T);
+  constexpr uint32_t TILE = kBlock * kSumVec * 16 / sizeof(T);
   const uint32_t eb = sizeof(T);
   unsigned long long total = 0;
   uint64_t b0 = 0;
