@@ -103,7 +103,7 @@ def main():
     import torch.distributed as dist
     from dpu_olap_amd import capi
     from dpu_olap_amd import datagen as dg
-    from dpu_olap_amd.dist_join import GpuLocalOps, distributed_join
+    from dpu_olap_amd.dist_join import DeviceBatches, GpuLocalOps, distributed_join
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -163,7 +163,8 @@ def main():
     ctx.gen_index_u32(pk.data_ptr(), n_local, first_row & 0xFFFFFFFF)
     ctx.gen_uniform_u32(x.data_ptr(), n_local, dg.SEED, dg.STREAM_X, first_row)
     batches = lambda k, p: [(k[b * BATCH_ROWS:(b + 1) * BATCH_ROWS], p[b * BATCH_ROWS:(b + 1) * BATCH_ROWS]) for b in range(my_batches)]
-    left, right = batches(fk, y), batches(pk, x)
+    # the batches carry their pointer / length tables, like Arrow record batches hold their buffer addresses
+    left, right = DeviceBatches(batches(fk, y)), DeviceBatches(batches(pk, x))
 
     # expected digest of the join result, from the inputs alone: pk is the global row
     # index, so x(fk) = gen32(STREAM_X, fk).  Order independent; summed over ranks.

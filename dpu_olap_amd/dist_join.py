@@ -36,6 +36,21 @@ def _i32(t: torch.Tensor) -> torch.Tensor:
     return t if t.dtype == torch.int32 else t.view(torch.int32)
 
 
+class DeviceBatches(list):
+    """A table's batches as (key, payload) tensor pairs that also carry their pointer and length tables,
+    built once -- like an Arrow RecordBatchVector, whose batches hold their buffer addresses: a Run() then
+    hands the tables over instead of asking thousands of tensors for their data_ptr() again."""
+
+    def __init__(self, pairs):
+        super().__init__(pairs)
+        self.keys = [p[0] for p in self]
+        self.payloads = [p[1] for p in self]
+        self.rows = [int(k.numel()) for k in self.keys]
+        self.key_table = capi.ptr_table([k.data_ptr() for k in self.keys])
+        self.payload_table = capi.ptr_table([p.data_ptr() for p in self.payloads])
+        self.rows_table = capi.u64_table(self.rows)
+
+
 class GpuLocalOps:
     """Local partition / join through libolap_gpu.so on torch CUDA tensors (int32 tensors
     carry the uint32 bit patterns; torch is only the allocator and the RCCL front end)."""
@@ -151,6 +166,22 @@ class GpuLocalOps:
             nhi.append(h + shift[k])
         span = max((b.data_ptr() - base) // 8 + int(b.numel()) for b in bufs)
         return base, span, nlo, nhi, rows
+
+    def join_batches(self, left: DeviceBatches, right: DeviceBatches, skip_bits: int = 0):
+        """join() on batches that carry their tables (DeviceBatches)."""
+        if not len(left) or not len(right):           # (an empty ctypes table still has one slot)
+            return self.join(left.keys, left.payloads, right.keys, right.payloads, skip_bits)
+        n = sum(left.rows)
+        out = [self.empty(n) for _ in range(3)]
+        torch.cuda.current_stream(self.device).synchronize()  # inputs come from torch's stream; do not wait for RCCL's
+        self.ctx.join_set_hash_skip_bits(skip_bits)
+        try:
+            got, stats = self.ctx.join_u32(left.key_table, left.payload_table, left.rows_table, right.key_table, right.payload_table,
+                                           right.rows_table, capi.MEM_DEVICE, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(),
+                                           n, capi.MEM_DEVICE)
+        finally:
+            self.ctx.join_set_hash_skip_bits(0)
+        return out[0][:got], out[1][:got], out[2][:got], stats
 
     def join(self, lfk, ly, rpk, rx, skip_bits: int = 0):
         lrows = [int(t.numel()) for t in lfk]
@@ -289,6 +320,9 @@ def distributed_join(ops, left_batches: Sequence, right_batches: Sequence, group
     """left_batches / right_batches: this rank's batches as (key, payload) tensor pairs.
     Returns (fk, y, x, info): this rank's shard of the join result (rows whose key it owns)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1 and isinstance(left_batches, DeviceBatches) and isinstance(right_batches, DeviceBatches) and hasattr(ops, "join_batches"):
+        fk, y, x, stats = ops.join_batches(left_batches, right_batches, 0)
+        return fk, y, x, {"world": 1, "stats": stats, "sent_rows": 0}
     lfk, ly = [b[0] for b in left_batches], [b[1] for b in left_batches]
     rpk, rx = [b[0] for b in right_batches], [b[1] for b in right_batches]
     if world == 1:
