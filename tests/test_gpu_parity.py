@@ -2,6 +2,8 @@
 ABI (include/olap_gpu.h via dpu_olap_amd.capi), against the CPU oracle, the
 reference's known-answer data and the Arrow golden vectors.  Bit-exact for all
 integer / index work."""
+import os
+
 import numpy as np
 import pytest
 
@@ -951,7 +953,10 @@ def test_join_drop_unmatched_is_an_inner_join(dev, space, size):
 
 
 # ----------------------------------------------------------- randomized shapes
-@pytest.mark.parametrize("seed", range(48))
+_FUZZ = int(os.environ.get("OLAP_FUZZ_SEEDS", "0"))   # soak runs: OLAP_FUZZ_SEEDS=500 pytest -m gpu -k random
+
+
+@pytest.mark.parametrize("seed", range(_FUZZ or 48))
 def test_join_random_shapes_and_plans_vs_oracle(dev, seed):
     """Seeded random join shapes (empty / one-row / ragged batches, full-range keys incl.
     0xFFFFFFFF and 0) under random radix plans and kernel variants (tile-staged or
@@ -1073,7 +1078,7 @@ def test_split_tuples_grouped_bucket_order(dev, obits, gbits, lbits):
                 k += 1
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(_FUZZ or 24))
 def test_scan_ops_random_shapes_vs_oracle(dev, seed):
     """Seeded random batch shapes (empty, one-row, tile-boundary, ragged, a long batch), the four
     element types, host or device operands: filter / sum / take / partition against the oracle
