@@ -230,8 +230,10 @@ def main():
         if dom:
             avg_ms = kern[dom]["ms"] / max(kern[dom]["launches"], 1)
             # a phase scope brackets exactly one kernel launch for hist / scatter / join-probe
-            per_launch_units = {"partition-scatter": n_local, "partition-hist": n_local, "join-probe": n_local}
-            alg_per_unit = {"partition-scatter": SCATTER_ALG_BYTES_PER_TUPLE, "partition-hist": 6, "join-probe": JOIN_ALG_BYTES_PER_PAIR}
+            per_launch_units = {"partition-scatter": n_local, "partition-scatter-claim": n_local, "partition-scatter-capacity": n_local,
+                                "partition-hist": n_local, "join-probe": n_local}
+            alg_per_unit = {"partition-scatter": SCATTER_ALG_BYTES_PER_TUPLE, "partition-scatter-claim": SCATTER_ALG_BYTES_PER_TUPLE,
+                            "partition-scatter-capacity": SCATTER_ALG_BYTES_PER_TUPLE, "partition-hist": 6, "join-probe": JOIN_ALG_BYTES_PER_PAIR}
             alg = alg_per_unit.get(dom, 16) * per_launch_units.get(dom, n_local)
             ach = alg / (avg_ms * 1e-3) / 1e9
             # HBM traffic per launch: PMC counters cannot be read from inside this process; the figure comes

@@ -30,6 +30,8 @@ enum Phase : int {
   PH_PART_HIST,
   PH_PART_SCAN,
   PH_PART_SCATTER,
+  PH_PART_SCATTER_CLAIM,  // pass 0 of the large-join plan (claimed allotments, no histogram)
+  PH_PART_SCATTER_CAP,    // last pass in the capacity layout (no histogram)
   PH_JOIN_PROBE,
   PH_GEN,
   PH_COUNT
@@ -86,10 +88,15 @@ struct olap_ctx {
   int direct_table = 1;    // collision-free direct-address LDS table when <= 14 hash bits remain (0: always probe)
   int wc_geometry = 2;     // 2: passes of <= 512 buckets use 512-thread workgroups on 4096-tuple tiles, two per CU
   int capacity_mode = 1;   // last radix pass without histogram (fixed-capacity regions + exact fallback)
+  int ring_scatter = 3;    // bit 0: claiming pass, bit 1: capacity pass: passes of <= 512 buckets run the ring scatter (ring_scatter.h): 128-byte lines, one workgroup per CU
+  int ring_tpt = 8;        // tuples per producer thread and tile of the ring scatter (8: 4096-tuple tiles, 4: 2048)
   int claim_mode = 1;      // pass 0 of a two-pass plan without histogram (claimed allotments): 0 off, 1 auto, 2 always
   int hash_skip_bits = 0;  // top hash bits already fixed by an upstream owner split
   int join_drop_unmatched = 0;       // 1: inner-join semantics (rows without a match are dropped, not an error)
   hipEvent_t right_ready = nullptr;  // one-shot: the next join waits for it before reading its right table
+  // diagnostics of the last join call (olap_get_counter)
+  uint64_t last_join_attempts = 0;        // 1 = the first plan went through
+  uint64_t last_join_region_overflows = 0;  // capacity / claimed regions that overflowed in the first attempt (skew -> exact rerun)
 
   // OLAP_MEM_HOST operands
   olap::Stager* stager = nullptr;
@@ -248,6 +255,37 @@ __device__ __forceinline__ uint64_t batch_row0(const ColView& v, uint32_t b) {
 }
 
 __device__ __forceinline__ unsigned lane_id() { return threadIdx.x & (kWave - 1); }
+
+// A value every lane of the wave holds alike (a batch-table entry read with a vector load): moved to
+// scalar registers, which frees two VGPRs per pointer in the partition kernels' tile loops.
+__device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
+
+// Loads through a pointer that was itself read from memory (the batch pointer tables).  The compiler
+// cannot tell that such a pointer is global and emits FLAT loads for it, which count in lgkmcnt as
+// well as vmcnt: every `s_waitcnt lgkmcnt(0)` in front of an s_barrier or an LDS access then waits for
+// the loads in flight.  These helpers state the address space, so the loads are global_load_*.
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+#define OLAP_GLOBAL __attribute__((address_space(1)))
+__device__ __forceinline__ uint4 gload4(const void* p) {
+  const u32x4_t v = *(const OLAP_GLOBAL u32x4_t*)p;
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uint2 gload2(const void* p) {
+  const u32x2_t v = *(const OLAP_GLOBAL u32x2_t*)p;
+  return make_uint2(v.x, v.y);
+}
+__device__ __forceinline__ void gstore2(void* p, uint2 v) {
+  u32x2_t t;
+  t.x = v.x;
+  t.y = v.y;
+  *(OLAP_GLOBAL u32x2_t*)p = t;
+}
+__device__ __forceinline__ uint32_t gload1(const void* p) { return *(const OLAP_GLOBAL uint32_t*)p; }
+__device__ __forceinline__ uint64_t gload1_u64(const void* p) { return *(const OLAP_GLOBAL uint64_t*)p; }
 
 __device__ __forceinline__ uint64_t wave_reduce_add(uint64_t x) {
 #pragma unroll

@@ -12,6 +12,7 @@ const char* const kPhaseNames[PH_COUNT] = {
     "copy-to-gpu",    "copy-from-gpu",  "sum",
     "filter-count",   "filter-compact", "take",
     "partition-hist", "partition-scan", "partition-scatter",
+    "partition-scatter-claim", "partition-scatter-capacity",
     "join-probe",     "gen"};
 
 int ws_begin(olap_ctx* ctx, uint64_t bytes) {

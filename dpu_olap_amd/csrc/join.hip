@@ -17,6 +17,7 @@
 #include "common.h"
 #include "probe_kernels.h"
 #include "radix_kernels.h"
+#include "ring_scatter.h"
 
 namespace olap {
 
@@ -130,8 +131,13 @@ static bool capacity_eligible(const olap_ctx* ctx, uint64_t rows, const PassPlan
 
 // Region size of the claiming scatter: the average bucket, 8 sigma of slack (uniform hash),
 // and what the workgroups may leave unused in their last allotments.  0: does not fit 32 bits.
+bool ring_ok(const olap_ctx* ctx, uint32_t fbits, int role);
 static uint32_t claim_cap(const olap_ctx* ctx, uint64_t rows, uint64_t F) {
-  const uint64_t kb = (uint64_t)ctx->compute_units * 2 > 256 ? (uint64_t)ctx->compute_units * 2 : 256;  // workgroups of pass 0
+  // allotments a pass-0 workgroup may leave unused per bucket, times the workgroups: one for the write-combining kernel
+  // (two workgroups per CU), up to three for the ring scatter (the one in use, the reserve, a claim in flight; one per CU)
+  const bool ring = ring_ok(ctx, (uint32_t)ceil_log2_u64(F), 1);
+  const uint64_t kb0 = (uint64_t)ctx->compute_units * (ring ? 3 : 2);
+  const uint64_t kb = kb0 > 256 ? kb0 : 256;
   const uint64_t avg = (rows + F - 1) / F;
   uint64_t sd = 1;
   while (sd * sd < avg) ++sd;
@@ -146,7 +152,8 @@ static bool claim_eligible(const olap_ctx* ctx, uint64_t rows, const PassPlan& p
   const uint64_t F = 1ull << plan.bits[0];
   if (!claim_cap(ctx, rows, F)) return false;
   if (ctx->claim_mode >= 2) return true;
-  const uint64_t kb = (uint64_t)ctx->compute_units * 2 > 256 ? (uint64_t)ctx->compute_units * 2 : 256;
+  const uint64_t kb0 = (uint64_t)ctx->compute_units * (ring_ok(ctx, plan.bits[0], 1) ? 3 : 2);
+  const uint64_t kb = kb0 > 256 ? kb0 : 256;
   return kb * kClaimChunk * F <= rows / 16;
 }
 
@@ -155,8 +162,15 @@ static bool pass_uses_geometry2(const olap_ctx* ctx, uint32_t fbits) {
   return ctx->scatter_variant == 0 && ctx->wc_geometry == 2 && !ctx->line16 && fbits <= 9;
 }
 
-// Tile size (rows per unit of the column view) pass 0 will use for `plan`.
-static uint32_t pass0_tile(const olap_ctx* ctx, const PassPlan& plan) {
+// The ring scatter (ring_scatter.h) serves the claiming pass 0 and the capacity-layout last pass of <= 512 buckets.
+bool ring_ok(const olap_ctx* ctx, uint32_t fbits, int role = 3) {  // role: 1 claiming pass, 2 capacity pass
+  return (ctx->ring_scatter & role) != 0 && ctx->scatter_variant == 0 && !ctx->line16 && (1u << fbits) <= (uint32_t)kRingFmax;
+}
+static uint32_t ring_tile(const olap_ctx* ctx) { return (uint32_t)(kRingProd * kWave * (ctx->ring_tpt == 4 ? 4 : 8)); }
+
+// Tile size (rows per unit of the column view) pass 0 will use for `plan`; `claim`: pass 0 is a claiming scatter.
+static uint32_t pass0_tile(const olap_ctx* ctx, const PassPlan& plan, bool claim = false) {
+  if (claim && ring_ok(ctx, plan.bits[0], 1)) return ring_tile(ctx);
   return pass_uses_geometry2(ctx, plan.bits[0]) ? kW2Tile : kPTile;
 }
 
@@ -212,6 +226,31 @@ static int launch_claim(olap_ctx* ctx, bool cols, bool g2, unsigned blocks, cons
                       : launch_claim_as<SRC_TUPLES, kW2Block, kW2Tile>(ctx, blocks, src, shift, fbits, out, co);
   return cols ? launch_claim_as<SRC_COLS, kWBlock, kPTile>(ctx, blocks, src, shift, fbits, out, co)
               : launch_claim_as<SRC_TUPLES, kWBlock, kPTile>(ctx, blocks, src, shift, fbits, out, co);
+}
+
+// ring scatter: claiming pass (CLAIM) or capacity-layout pass, 1024 threads, one workgroup per CU
+template <int SRC, bool CLAIM, int TPT>
+static int launch_ring_as(olap_ctx* ctx, unsigned blocks, const PassSrc& src, uint32_t shift, uint32_t fbits, uint2* out, const CapOut& co,
+                          const ClaimOut& cq) {
+  constexpr uint32_t kLds = RingCfg<kRingFmax, kRingLine, kRingBlock, kRingProd>::kBytes;
+  auto kernel = k_part_scatter_ring<SRC, CLAIM, kRingFmax, kRingLine, kRingBlock, kRingProd, TPT>;
+  OLAP_TRY(allow_lds(ctx, reinterpret_cast<const void*>(kernel), kLds));
+  hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kRingBlock), kLds, ctx->stream, src, shift, fbits, out, co, cq);
+  OLAP_HIP(ctx, hipGetLastError());
+  return OLAP_OK;
+}
+
+static int launch_ring(olap_ctx* ctx, bool cols, bool claim, unsigned blocks, const PassSrc& src, uint32_t shift, uint32_t fbits, uint2* out,
+                       const CapOut& co, const ClaimOut& cq) {
+  const bool t4 = ctx->ring_tpt == 4;
+  if (claim) {
+    if (cols) return t4 ? launch_ring_as<SRC_COLS, true, 4>(ctx, blocks, src, shift, fbits, out, co, cq)
+                        : launch_ring_as<SRC_COLS, true, 8>(ctx, blocks, src, shift, fbits, out, co, cq);
+    return t4 ? launch_ring_as<SRC_TUPLES, true, 4>(ctx, blocks, src, shift, fbits, out, co, cq)
+              : launch_ring_as<SRC_TUPLES, true, 8>(ctx, blocks, src, shift, fbits, out, co, cq);
+  }
+  return t4 ? launch_ring_as<SRC_TUPLES, false, 4>(ctx, blocks, src, shift, fbits, out, co, cq)
+            : launch_ring_as<SRC_TUPLES, false, 8>(ctx, blocks, src, shift, fbits, out, co, cq);
 }
 
 // tile-staged scatter without residues (scatter_variant = 1, A/B)
@@ -305,9 +344,12 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
     uint64_t blocks, bseg;
     const bool cols = i == 0 && !tuple_in;
     const bool g2 = wc && pass_uses_geometry2(ctx, fbits);  // 512 threads, 4096-tuple tiles, 2 workgroups per CU
+    const bool claim_pass = claim && i == 0 && plan.passes == 2 && wc && !pre;  // claiming scatter: no histogram
+    const bool ring_claim = claim_pass && ring_ok(ctx, fbits, 1);
+    const bool ring_cap = capm && i == plan.passes - 1 && !(pre_ranges && i == 0) && ring_ok(ctx, fbits, 2);
     if (cols) {
       const uint64_t tiles = cs.view.total_units;
-      uint64_t nb = (uint64_t)ctx->compute_units * ((wc && !g2) ? 1 : 2);
+      uint64_t nb = (uint64_t)ctx->compute_units * ((ring_claim || (wc && !g2)) ? 1 : 2);
       if (nb > tiles) nb = tiles;
       if (nb == 0) nb = 1;
       src.tiles_per_block = (tiles + nb - 1) / nb;
@@ -324,6 +366,7 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
       }
       src.chunk_split = chunk_split;
       bseg = ranged ? pre->chunks * chunk_split : (capm && i == plan.passes - 1) ? 1 : seg_blocks(ctx, n_seg);
+      if (ring_claim) bseg = std::max<uint64_t>(1, ((uint64_t)ctx->compute_units + n_seg - 1) / n_seg);  // one workgroup per CU
       blocks = n_seg * bseg;
       src.tuples = in_tuples;
       src.seg_off = seg_in;
@@ -332,15 +375,16 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
       src.blk_range = ranged ? pre_ranges : nullptr;
     }
     if (blocks > 0x7FFFFFFFull) return ctx->fail(OLAP_ERR_INVALID, "partition grid too large");
-    if (claim && i == 0 && plan.passes == 2 && wc && !pre) {  // claiming scatter: no histogram
+    if (claim_pass) {
       const uint32_t ccap = claim_cap(ctx, rows, F);
       uint32_t* cursor = (uint32_t*)ws_alloc(ctx, F * 4);
       if (!cursor || !ccap) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (claim cursors)");
       OLAP_HIP(ctx, hipMemsetAsync(cursor, 0, F * 4, ctx->stream));
       {
-        PhaseScope ps(ctx, PH_PART_SCATTER);
+        PhaseScope ps(ctx, PH_PART_SCATTER_CLAIM);
         const ClaimOut co{ccap, cursor, d_overflow};
-        OLAP_TRY(launch_claim(ctx, cols, g2, (unsigned)blocks, src, shift, fbits, out, co));
+        if (ring_claim) OLAP_TRY(launch_ring(ctx, cols, true, (unsigned)blocks, src, shift, fbits, out, CapOut{}, co));
+        else OLAP_TRY(launch_claim(ctx, cols, g2, (unsigned)blocks, src, shift, fbits, out, co));
         OLAP_HIP(ctx, hipGetLastError());
       }
       src.seg_cnt = cursor;  // the next pass reads regions of `ccap` tuples and skips the fillers
@@ -358,15 +402,16 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
       so->cnt = (uint32_t*)ws_alloc(ctx, n_seg * F * 4);
       so->dense = (uint64_t*)ws_alloc(ctx, n_seg * F * 8);
       if (!so->cnt || !so->dense) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (capacity tables)");
-      PhaseScope ps(ctx, PH_PART_SCATTER);
+      PhaseScope ps(ctx, PH_PART_SCATTER_CAP);
       uint64_t* seg_total = nullptr;
       if (claimed_input) {
         seg_total = (uint64_t*)ws_alloc(ctx, n_seg * 8);
         if (!seg_total) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (segment totals)");
       }
       CapOut co{so->cap, so->cnt, so->dense, d_overflow, seg_total};
-      OLAP_TRY((launch_scatter<true>(ctx, /*cols=*/false, g2, fbits <= 9 && ctx->line16, (unsigned)blocks, src, shift, fbits, nullptr,
-                                     nullptr, out, co)));
+      if (ring_cap) OLAP_TRY(launch_ring(ctx, /*cols=*/false, false, (unsigned)blocks, src, shift, fbits, out, co, ClaimOut{}));
+      else OLAP_TRY((launch_scatter<true>(ctx, /*cols=*/false, g2, fbits <= 9 && ctx->line16, (unsigned)blocks, src, shift, fbits, nullptr,
+                                          nullptr, out, co)));
       OLAP_HIP(ctx, hipGetLastError());
       if (claimed_input) {  // the segments' dense starts were unknown to the scatter: number the partitions now
         hipLaunchKernelGGL(k_dense_fix, dim3((unsigned)n_seg), dim3(1024), 0, ctx->stream, (const uint64_t*)seg_total, (uint32_t)F,
@@ -484,8 +529,8 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
   OLAP_TRY(pinned_begin(ctx, pin));
   OLAP_TRY(ws_begin(ctx, need));
   ColumnSet lcs, rcs;
-  if (!in.l_tuples) OLAP_TRY(build_column_set(ctx, lcols, l_pay ? 2 : 1, eb, lrows, lnb, in_mem, pass0_tile(ctx, plan), &lcs));
-  if (!in.r_tuples) OLAP_TRY(build_column_set(ctx, rcols, r_pay ? 2 : 1, eb, rrows, rnb, in_mem, pass0_tile(ctx, plan), &rcs));
+  if (!in.l_tuples) OLAP_TRY(build_column_set(ctx, lcols, l_pay ? 2 : 1, eb, lrows, lnb, in_mem, pass0_tile(ctx, plan, lclaim), &lcs));
+  if (!in.r_tuples) OLAP_TRY(build_column_set(ctx, rcols, r_pay ? 2 : 1, eb, rrows, rnb, in_mem, pass0_tile(ctx, plan, rclaim), &rcs));
   uint2* tmp0 = plan.passes >= 2 ? (uint2*)ws_alloc(ctx, (tmp_tuples + 2) * 8) : nullptr;
   uint2* tmp1 = plan.passes >= 3 ? (uint2*)ws_alloc(ctx, (maxN + 2) * 8) : nullptr;
   uint2* Lt = (uint2*)ws_alloc(ctx, (lt_tuples + 2) * 8);
@@ -637,8 +682,12 @@ static int join_run(olap_ctx* ctx, const JoinIn& jin, uint64_t NL, uint64_t NR, 
   unsigned long long counters[5] = {0, 0, 0, 0, 0};
   uint64_t kept_rows = NL;
   bool allow_capacity = true;
+  ctx->last_join_attempts = 0;
+  ctx->last_join_region_overflows = 0;
   for (int attempt = 0; attempt < 4; ++attempt) {
+    ++ctx->last_join_attempts;
     OLAP_TRY(join_once(ctx, jin, out_fk, out_y, out_x, out_mem, NL, NR, bits, allow_capacity, stats, counters, &kept_rows));
+    if (attempt == 0) ctx->last_join_region_overflows = counters[4];
     if (counters[4]) {  // a fixed-capacity region overflowed (skew): redo with exact partitioning
       allow_capacity = false;
       continue;
@@ -690,6 +739,16 @@ int olap_set_tuning(olap_ctx* ctx, const char* key, int value) {
     ctx->take_variant = value;
     return OLAP_OK;
   }
+  if (!std::strcmp(key, "ring_scatter")) {
+    if (value < 0 || value > 3) return ctx->fail(OLAP_ERR_INVALID, "ring_scatter must be 0 (off), 1 (claiming pass), 2 (capacity pass) or 3 (both)");
+    ctx->ring_scatter = value;
+    return OLAP_OK;
+  }
+  if (!std::strcmp(key, "ring_tpt")) {
+    if (value != 4 && value != 8) return ctx->fail(OLAP_ERR_INVALID, "ring_tpt must be 4 or 8");
+    ctx->ring_tpt = value;
+    return OLAP_OK;
+  }
   if (!std::strcmp(key, "claim_mode")) {
     if (value < 0 || value > 2) return ctx->fail(OLAP_ERR_INVALID, "claim_mode must be 0 (off), 1 (auto) or 2 (always)");
     ctx->claim_mode = value;
@@ -706,6 +765,14 @@ int olap_set_tuning(olap_ctx* ctx, const char* key, int value) {
     return OLAP_OK;
   }
   return ctx->fail(OLAP_ERR_INVALID, "unknown tuning key '%s'", key);
+}
+
+int olap_get_counter(olap_ctx* ctx, const char* name, uint64_t* out_value) {
+  if (!ctx || !name || !out_value) return OLAP_ERR_INVALID;
+  if (!std::strcmp(name, "join_attempts")) *out_value = ctx->last_join_attempts;
+  else if (!std::strcmp(name, "join_region_overflows")) *out_value = ctx->last_join_region_overflows;
+  else return ctx->fail(OLAP_ERR_INVALID, "unknown counter '%s'", name);
+  return OLAP_OK;
 }
 
 int olap_join_set_hash_skip_bits(olap_ctx* ctx, int bits) {

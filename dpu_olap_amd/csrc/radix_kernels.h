@@ -154,10 +154,10 @@ __device__ __forceinline__ uint32_t load_tile(const PassSrc& s, const TileRange&
     cur.local_unit = l.local_unit;
     if (l.batch != cur.batch) {  // workgroup-uniform
       cur.batch = l.batch;
-      cur.kp = (const uint32_t*)s.key_ptrs[l.batch];
-      cur.pp = s.pay_ptrs ? (const uint32_t*)s.pay_ptrs[l.batch] : nullptr;
-      cur.rows = batch_rows(s.v, l.batch);
-      cur.row0 = batch_row0(s.v, l.batch);
+      cur.kp = (const uint32_t*)uniform_u64((uint64_t)s.key_ptrs[l.batch]);
+      cur.pp = s.pay_ptrs ? (const uint32_t*)uniform_u64((uint64_t)s.pay_ptrs[l.batch]) : nullptr;
+      cur.rows = uniform_u64(batch_rows(s.v, l.batch));
+      cur.row0 = uniform_u64(batch_row0(s.v, l.batch));
       cur.units = (cur.rows + TILE - 1) / TILE;
     }
     const uint64_t rows = cur.rows;
@@ -170,10 +170,10 @@ __device__ __forceinline__ uint32_t load_tile(const PassSrc& s, const TileRange&
     if (fast) {
       uint4 kv[TPT / 4], pv[TPT / 4];
 #pragma unroll
-      for (int j = 0; j < TPT / 4; ++j) kv[j] = ((const uint4*)kp)[j * BLOCK + threadIdx.x];
+      for (int j = 0; j < TPT / 4; ++j) kv[j] = gload4((const uint4*)kp + j * BLOCK + threadIdx.x);
       if (WANT_PAYLOAD && pp) {
 #pragma unroll
-        for (int j = 0; j < TPT / 4; ++j) pv[j] = ((const uint4*)pp)[j * BLOCK + threadIdx.x];
+        for (int j = 0; j < TPT / 4; ++j) pv[j] = gload4((const uint4*)pp + j * BLOCK + threadIdx.x);
       }
 #pragma unroll
       for (int j = 0; j < TPT / 4; ++j) {
@@ -204,8 +204,8 @@ __device__ __forceinline__ uint32_t load_tile(const PassSrc& s, const TileRange&
         for (int k = 0; k < 4; ++k) {
           const uint32_t idx = (j * BLOCK + threadIdx.x) * 4 + k;
           const bool ok = idx < n;
-          key[4 * j + k] = ok ? kp[idx] : 0u;
-          if (WANT_PAYLOAD) pay[4 * j + k] = ok ? (pp ? pp[idx] : rowid0 + idx) : 0u;
+          key[4 * j + k] = ok ? gload1(kp + idx) : 0u;
+          if (WANT_PAYLOAD) pay[4 * j + k] = ok ? (pp ? gload1(pp + idx) : rowid0 + idx) : 0u;
           mask |= (ok ? 1u : 0u) << (4 * j + k);
         }
       }

@@ -96,7 +96,9 @@ int olap_memset(olap_ctx* ctx, void* dst_device, int byte_value, uint64_t bytes)
  * bracketed by HIP events on the context's stream; the accumulated device time
  * and launch count per phase are returned.  Phase names: "copy-to-gpu",
  * "copy-from-gpu", "sum", "filter-count", "filter-compact", "take",
- * "partition-hist", "partition-scan", "partition-scatter", "join-probe", "gen". */
+ * "partition-hist", "partition-scan", "partition-scatter" (exact layout, behind a histogram),
+ * "partition-scatter-claim" (pass 0 without histogram), "partition-scatter-capacity" (last pass
+ * without histogram), "join-probe", "gen". */
 int olap_set_profiling(olap_ctx* ctx, int enabled);
 int olap_reset_timers(olap_ctx* ctx);
 /* Fills up to `cap` entries; *out_n = number of phases with launches. names[i]
@@ -262,11 +264,21 @@ int olap_join_configure(olap_ctx* ctx, int radix_bits_total, int max_bits_per_pa
  *   line16             0 64-byte lines (default) | 1 128-byte lines for passes of <= 512 buckets (one workgroup per CU)
  *   capacity_mode      1 last pass without histogram, fixed-capacity regions (default) | 0 exact layout
  *   claim_mode         1 pass 0 of large two-pass plans as a claiming scatter (default) | 0 never | 2 always
+ *   ring_scatter       3 claiming AND capacity passes of <= 512 buckets run the ring scatter: per-bucket LDS rings, 128-byte
+ *                      lines, one 1024-thread workgroup per CU (default) | 1 claiming pass only | 2 capacity pass only
+ *                      | 0 the write-combining kernels
+ *   ring_tpt           8 (default) | 4 tuples per producer thread and tile of the ring scatter
  *   direct_table       1 direct-address LDS table when <= 14 hash bits remain (default) | 0 probing table
  *   take_variant       0 automatic | 1 never the LDS-window kernel | 2 never small tiles
  *   host_stage         1 pinned ring + copy threads for OLAP_MEM_HOST operands (default) | 0 plain hipMemcpyAsync
  *   host_copy_threads  0 = min(hardware threads, 8) */
 int olap_set_tuning(olap_ctx* ctx, const char* key, int value);
+/* Diagnostics of the LAST join call on this context (the reference has no analog: its regions are sized by a
+ * histogram round trip, host/join/join_dpu.cc:54-66).  Names:
+ *   "join_attempts"          1 = the first plan went through; > 1 = it was redone (exact partitioning after a region
+ *                            overflow, or more radix bits after an LDS-table overflow)
+ *   "join_region_overflows"  (workgroup, bucket) regions of the histogram-free passes that overflowed in the first attempt */
+int olap_get_counter(olap_ctx* ctx, const char* name, uint64_t* out_value);
 /* Multi-GPU: when the inputs of this context were already split by the top
  * `bits` bits of wang_hash(key) (olap_partition_u32 with nr_partitions = #GPUs,
  * one partition per GPU), all keys here share those bits; the join's own radix

@@ -952,6 +952,100 @@ def test_join_drop_unmatched_is_an_inner_join(dev, space, size):
     assert get(r3["fk"]).size == 0
 
 
+@pytest.mark.parametrize("tpt", [8, 4])
+@pytest.mark.parametrize("shape", ["uniform", "clustered_left", "clustered_both", "runs", "ragged"])
+def test_join_ring_scatter_vs_digest(dev, shape, tpt):
+    """The ring scatter (csrc/ring_scatter.h: per-bucket LDS rings, 128-byte lines, producer and
+    flusher waves) as claiming pass 0 AND as capacity-layout last pass, forced at 2^25 rows with an
+    8 + 8 bit plan.  clustered_*: the rows are ordered by their hash, so every tile falls into ONE
+    bucket -- each tile takes the hot path (ring overflow -> direct range writes) while the bucket
+    sizes stay balanced, i.e. nothing overflows and the ring kernels' output is what is checked;
+    runs: bursts of 64 rows per bucket; ragged: odd batch lengths.  Checked: row digest, that the two
+    ring phases ran (and no histogram pass), partition-major output."""
+    o = _ops()
+    from dpu_olap_amd import datagen as dg
+    rows, nb = ((1 << 20), 32) if shape != "ragged" else ((1 << 20) - 4321, 33)
+    n = rows * nb
+    rng = np.random.default_rng(7)
+    pk = np.arange(n, dtype=np.uint32) * np.uint32(2654435761) + np.uint32(12345)   # a permutation of distinct keys
+    x = dg.uniform_u32(n, dg.SEED, dg.STREAM_X, 0)
+    fk = pk[rng.integers(0, n, size=n)]
+    y = dg.uniform_u32(n, dg.SEED, dg.STREAM_Y, 0)
+    if shape.startswith("clustered"):
+        order = np.argsort(oracle.wang_hash_np(fk), kind="stable")
+        fk, y = fk[order], y[order]
+        if shape == "clustered_both":
+            order = np.argsort(oracle.wang_hash_np(pk), kind="stable")
+            pk, x = pk[order], x[order]
+    elif shape == "runs":   # bursts: blocks of 64 consecutive rows share their top 8 hash bits
+        order = np.argsort(oracle.wang_hash_np(fk) >> np.uint32(24), kind="stable")
+        blocks = order.reshape(-1, 64)
+        blocks = blocks[rng.permutation(blocks.shape[0])]
+        fk, y = fk[blocks.reshape(-1)], y[blocks.reshape(-1)]
+    xs = dg.uniform_u32(n, dg.SEED, dg.STREAM_X, 0)                              # x of key number i, before any reordering
+    exp_x = xs[(fk - np.uint32(12345)) * np.uint32(pow(2654435761, -1, 1 << 32))]   # i = (key - 12345) / 2654435761 mod 2^32
+    d = {k: dev.to_device(v) for k, v in (("fk", fk), ("y", y), ("pk", pk), ("x", x), ("exp", exp_x))}
+    expect = dev.checksum_rows3_u32(d["fk"].ptr, d["y"].ptr, d["exp"].ptr, n)
+    batch = lambda c, b: o.DeviceArray(d[c].ptr + 4 * b * rows, rows, "uint32")
+    dev.join_configure(16, 8)
+    dev.set_tuning("claim_mode", 2)
+    dev.set_tuning("ring_scatter", 3)
+    dev.set_tuning("ring_tpt", tpt)
+    dev.reset_timers()
+    try:
+        j = o.JoinGpu(dev, [(batch("fk", b), batch("y", b)) for b in range(nb)],
+                      [(batch("pk", b), batch("x", b)) for b in range(nb)]).Prepare()
+        out = j.Run()
+        timers = j.Timers()
+    finally:
+        dev.join_configure(-1, 0)
+        dev.set_tuning("claim_mode", 1)
+        dev.set_tuning("ring_tpt", 8)
+    assert out["fk"].rows == n and j.stats["missing_keys"] == 0, j.stats
+    assert j.stats["radix_bits"][:2] == [8, 8], j.stats
+    assert dev.checksum_rows3_u32(out["fk"].ptr, out["y"].ptr, out["x"].ptr, n) == expect
+    assert timers.get("partition-scatter-claim", 0) and timers.get("partition-scatter-capacity", 0), timers
+    assert dev.get_counter("join_attempts") == 1 and dev.get_counter("join_region_overflows") == 0   # no exact rerun behind the result
+    assert not timers.get("partition-hist", 0), timers
+    ofk = dev.to_host(out["fk"])
+    part = oracle.wang_hash_np(ofk) >> np.uint32(16)
+    assert (np.diff(part.astype(np.int64)) >= 0).all()
+    for c in list(d.values()) + list(out.values()):
+        dev.release(o.DeviceArray(c.ptr, 0))
+
+
+def test_join_ring_scatter_skew_falls_back_to_exact(dev):
+    """Ring scatter with a skewed probe side (1024 distinct foreign keys): the claimed regions / capacity
+    regions overflow, the kernels drop what does not fit and raise the overflow counter, and the join is
+    redone with exact passes.  The digest must match."""
+    o = _ops()
+    from dpu_olap_amd import datagen as dg
+    rows, nb = 1 << 20, 32
+    n = rows * nb
+    cols = {k: dev.empty(n, "uint32") for k in ("fk", "y", "pk", "x", "exp")}
+    dev.gen_fk_u32(cols["fk"].ptr, n, dg.SEED, dg.STREAM_FK, 0, n, 1024)
+    dev.gen_uniform_u32(cols["y"].ptr, n, dg.SEED, dg.STREAM_Y, 0)
+    dev.gen_index_u32(cols["pk"].ptr, n, 0)
+    dev.gen_uniform_u32(cols["x"].ptr, n, dg.SEED, dg.STREAM_X, 0)
+    dev.gen_uniform_u32_at(cols["exp"].ptr, cols["fk"].ptr, n, dg.SEED, dg.STREAM_X)
+    expect = dev.checksum_rows3_u32(cols["fk"].ptr, cols["y"].ptr, cols["exp"].ptr, n)
+    batch = lambda c, b: o.DeviceArray(cols[c].ptr + 4 * b * rows, rows, "uint32")
+    dev.join_configure(16, 8)
+    dev.set_tuning("claim_mode", 2)
+    try:
+        j = o.JoinGpu(dev, [(batch("fk", b), batch("y", b)) for b in range(nb)],
+                      [(batch("pk", b), batch("x", b)) for b in range(nb)]).Prepare()
+        out = j.Run()
+    finally:
+        dev.join_configure(-1, 0)
+        dev.set_tuning("claim_mode", 1)
+    assert out["fk"].rows == n
+    assert dev.get_counter("join_attempts") == 2 and dev.get_counter("join_region_overflows") > 0   # the fallback did run
+    assert dev.checksum_rows3_u32(out["fk"].ptr, out["y"].ptr, out["x"].ptr, n) == expect
+    for c in list(cols.values()) + list(out.values()):
+        dev.release(o.DeviceArray(c.ptr, 0))
+
+
 # ----------------------------------------------------------- randomized shapes
 _FUZZ = int(os.environ.get("OLAP_FUZZ_SEEDS", "0"))   # soak runs: OLAP_FUZZ_SEEDS=500 pytest -m gpu -k random
 
@@ -991,7 +1085,8 @@ def test_join_random_shapes_and_plans_vs_oracle(dev, seed):
     if bits >= 0 and nr >> bits > 6000:
         bits = -1                               # keep build partitions inside the probing table
     knobs = {"scatter_variant": int(rng.integers(2)), "capacity_mode": int(rng.integers(2)), "claim_mode": int(rng.choice([0, 2])),
-             "direct_table": int(rng.integers(2)), "wc_geometry": int(rng.choice([1, 2])), "line16": int(rng.integers(2))}
+             "direct_table": int(rng.integers(2)), "wc_geometry": int(rng.choice([1, 2])), "line16": int(rng.integers(2)),
+             "ring_scatter": int(rng.integers(4)), "ring_tpt": int(rng.choice([4, 8]))}
     per_pass = int(rng.choice([0, 0, 3, 5, 8, 10]))
     if per_pass and max(bits, 8) > 4 * per_pass:
         per_pass = 0                            # more than 4 passes is a configuration error
@@ -1003,7 +1098,8 @@ def test_join_random_shapes_and_plans_vs_oracle(dev, seed):
         r = j.Run()
     finally:
         dev.join_configure(-1, 0)
-        for k, v in {"scatter_variant": 0, "capacity_mode": 1, "claim_mode": 1, "direct_table": 1, "wc_geometry": 2, "line16": 0}.items():
+        for k, v in {"scatter_variant": 0, "capacity_mode": 1, "claim_mode": 1, "direct_table": 1, "wc_geometry": 2, "line16": 0,
+                     "ring_scatter": 3, "ring_tpt": 8}.items():
             dev.set_tuning(k, v)
     get = (lambda a: a) if space == "host" else dev.to_host
     got = sort_rows(get(r["fk"]), get(r["y"]), get(r["x"]))
