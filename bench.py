@@ -50,6 +50,10 @@ def parse():
     ap.add_argument("--scatter-variant", type=int, default=0, help="tuning: 0 write-combining, 1 tile-staged")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=INT", help="olap_set_tuning knob for A/B runs (e.g. claim_mode=0)")
     ap.add_argument("--cpu-sf", type=int, default=0, help="scale factor of the bounded CPU sample (default: auto)")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="N=1 only: a process group of one rank over RCCL, and the join takes the multi-GPU route (fused split -> "
+                         "all_to_all_single -> pre-split join) -- rehearses the exchange code on a one-GPU box")
+    ap.add_argument("--exchange-order", default="", help="multi-GPU: issue order of the exchanges, 'table' or 'group' (default: dist_join's)")
     return ap.parse_args()
 
 
@@ -122,15 +126,26 @@ def main():
     dev_index = 0 if share_gpu else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
+    force_exchange = args.force_exchange or os.environ.get("OLAP_BENCH_FORCE_EXCHANGE") == "1"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
+    elif force_exchange:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        kw = {"device_id": device} if backend == "nccl" else {}
+        dist.init_process_group(backend, init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, **kw)
     ctx = capi.Context(dev_index)
     info = ctx.device_info()
     ops = GpuLocalOps(ctx, device)
+    ops.force_exchange = force_exchange
+    if args.exchange_order:
+        ops.exchange_order = args.exchange_order
     ctx.join_configure(args.radix_bits, args.max_bits_per_pass)
     ctx.set_tuning("scatter_variant", args.scatter_variant)
     for kv in args.tune:
@@ -157,7 +172,11 @@ def main():
 
     def col():
         return torch.empty(n_local, dtype=torch.int32, device=device)
-    fk, y, pk, x = col(), col(), col(), col()
+    # the four input columns: one allocation, carved with a skew, so that the columns are not an exact power of two
+    # apart (GpuLocalOps.empty_columns; OLAP_BENCH_COLUMN_SKEW=0 for separate back-to-back allocations, A/B)
+    if os.environ.get("OLAP_BENCH_COLUMN_SKEW", "1") == "0":
+        ops.column_skew_bytes = 0
+    fk, y, pk, x = ops.empty_columns(n_local, 4)
     ctx.gen_fk_u32(fk.data_ptr(), n_local, dg.SEED, dg.STREAM_FK, first_row, BATCH_ROWS, BATCH_ROWS)
     ctx.gen_uniform_u32(y.data_ptr(), n_local, dg.SEED, dg.STREAM_Y, first_row)
     ctx.gen_index_u32(pk.data_ptr(), n_local, first_row & 0xFFFFFFFF)
@@ -188,9 +207,14 @@ def main():
         return distributed_join(ops, left, right, timers=host_wall)
 
     result = None
-    for _ in range(args.warmup):
+    cold_first_step_ms = None      # the very first join of this context: the scratch arena (~217 GiB at SF=2048) is allocated in it
+    for w in range(args.warmup):
         result = None
+        tc = time.perf_counter()
         result = step()
+        if w == 0:
+            sync_all()
+            cold_first_step_ms = (time.perf_counter() - tc) * 1e3
     sync_all()
     ctx.reset_timers()
     host_wall.clear()
@@ -200,6 +224,8 @@ def main():
         result = step()
     sync_all()
     dt = time.perf_counter() - t0
+    if cold_first_step_ms is None and args.steps == 1:
+        cold_first_step_ms = dt * 1e3          # no warm-up: the one timed step was the cold one
     timers = ctx.timers()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -223,38 +249,57 @@ def main():
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = 2 * n_total / (dt / args.steps) / 1e6
-        # dominant kernel from the live HIP-event timers of the timed region
-        kern = {k: v for k, v in timers.items() if k.startswith(("partition-", "join-"))}
-        dom = max(kern, key=lambda k: kern[k]["ms"]) if kern else None
-        roofline = None
-        if dom:
-            avg_ms = kern[dom]["ms"] / max(kern[dom]["launches"], 1)
-            # a phase scope brackets exactly one kernel launch for hist / scatter / join-probe
-            per_launch_units = {"partition-scatter": n_local, "partition-scatter-claim": n_local, "partition-scatter-capacity": n_local,
-                                "partition-hist": n_local, "join-probe": n_local}
-            alg_per_unit = {"partition-scatter": SCATTER_ALG_BYTES_PER_TUPLE, "partition-scatter-claim": SCATTER_ALG_BYTES_PER_TUPLE,
-                            "partition-scatter-capacity": SCATTER_ALG_BYTES_PER_TUPLE, "partition-hist": 6, "join-probe": JOIN_ALG_BYTES_PER_PAIR}
-            alg = alg_per_unit.get(dom, 16) * per_launch_units.get(dom, n_local)
-            ach = alg / (avg_ms * 1e-3) / 1e9
-            # HBM traffic per launch: PMC counters cannot be read from inside this process; the figure comes
-            # from the committed rocprofv3 PMC passes of this same command (profiles/), only for the config
-            # they were taken on, else null.
-            traffic = None
+        # Per-kernel figures from the live HIP-event timers of the timed region (every phase scope below brackets exactly
+        # ONE kernel launch on the context's stream); the kernel names are what rocprofv3 --kernel-trace prints.
+        alg_per_unit = {"partition-scatter": SCATTER_ALG_BYTES_PER_TUPLE, "partition-scatter-claim": SCATTER_ALG_BYTES_PER_TUPLE,
+                        "partition-scatter-capacity": SCATTER_ALG_BYTES_PER_TUPLE, "partition-hist": 4, "join-probe": JOIN_ALG_BYTES_PER_PAIR}
+        # HBM traffic per launch: PMC counters cannot be read from inside this process; the figures come from the committed
+        # rocprofv3 PMC passes of this same command (scripts/profile_bench.sh -> profiles/), only for the config they were
+        # taken on, else null.
+        traffic_src, traffic_by_kernel = None, {}
+        for cand in ("r2_traffic_sf2048.json", "r1_traffic_sf2048.json"):
             try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic_sf2048.json")))
-                if tj.get("sf") == sf and tj.get("n_gpus") == world and not args.radix_bits >= 0:
-                    traffic = tj["phases"].get(dom)
+                tj = json.load(open(os.path.join(ROOT, "profiles", cand)))
             except Exception:
-                traffic = None
-            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                        "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                        "traffic_source": "profiles/r1_traffic_sf2048.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2)" if traffic else None,
-                        "avg_launch_ms": round(avg_ms, 4), "launches": kern[dom]["launches"],
-                        "algorithmic_bytes_per_launch": alg,
+                continue
+            if tj.get("sf") == sf and tj.get("n_gpus") == world and not args.radix_bits >= 0 and not args.tune:
+                traffic_src, traffic_by_kernel = f"profiles/{cand}", tj.get("kernels", {})
+                break
+        kernels = []
+        for ph, v in timers.items():
+            if ph not in alg_per_unit or not v["launches"]:
+                continue
+            avg_ms = v["ms"] / v["launches"]
+            alg = alg_per_unit[ph] * n_local
+            ach = alg / (avg_ms * 1e-3) / 1e9
+            name = ctx.phase_kernel(ph)
+            kernels.append({"phase": ph, "kernel": name, "launches_per_step": v["launches"] / args.steps, "avg_launch_ms": round(avg_ms, 4),
+                            "total_ms_per_step": round(v["ms"] / args.steps, 3), "algorithmic_bytes_per_launch": alg,
+                            "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBPS, 4),
+                            "traffic": (traffic_by_kernel.get(name) or {}).get("bytes_per_launch")})
+        kernels.sort(key=lambda k: -k["total_ms_per_step"])
+        roofline = None
+        if kernels:
+            d = kernels[0]   # the kernel with the largest total time per step
+            roofline = {"bound": "hbm", "kernel": d["kernel"], "phase": d["phase"], "achieved": d["achieved"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": d["frac"], "traffic": d["traffic"],
+                        "traffic_source": (traffic_src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2)") if d["traffic"] else None,
+                        "avg_launch_ms": d["avg_launch_ms"], "launches": int(round(d["launches_per_step"] * args.steps)),
+                        "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
                         # the same rate against what a pure streaming read reaches on this chip (k_sum / k_part_hist:
                         # 6.0-6.2 TB/s) -- the "HBM read roofline" of BASELINE.json's target
                         "measured_read_ceiling": MEASURED_READ_CEILING_GBPS,
-                        "frac_of_read_ceiling": round(ach / MEASURED_READ_CEILING_GBPS, 4)}
+                        "frac_of_read_ceiling": round(d["achieved"] / MEASURED_READ_CEILING_GBPS, 4)}
+        # The whole join on MEASURED traffic (a k-pass radix join moves several times its compulsory bytes; the 60 %
+        # target is read on the bytes the kernels actually move): sum over the join's kernels of PMC bytes per launch x launches
+        # per join, over the wall time of a step.
+        measured = None
+        if traffic_by_kernel and all(k["traffic"] for k in kernels):
+            per_join = sum(k["traffic"] * k["launches_per_step"] for k in kernels)
+            ach = per_join / (dt / args.steps) / 1e9
+            measured = {"bound": "hbm", "bytes_per_join": int(per_join), "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": round(ach / HBM_PEAK_GBPS, 4), "source": traffic_src,
+                        "note": "sum over the join's kernels of (FETCH_SIZE x2 + WRITE_SIZE) per launch x launches per join / wall time per step"}
         whole = JOIN_ALG_BYTES_PER_PAIR * n_total / (dt / args.steps) / 1e9
         line = {
             "metric": "Mrows/s for BM_Join (build+probe) at SF=2048",
@@ -264,11 +309,17 @@ def main():
             "config": {"workload": f"BM_Join u32 PK-FK SF={sf}: {sf} batches x 2Mi rows per side ({n_total} rows/side), "
                                    f"{world} x MI355X" + (", hash-owner split + all-to-all" if world > 1 else ""),
                        "sf": sf, "rows_per_side": n_total, "batch_rows": BATCH_ROWS, "radix": jinfo["stats"],
-                       "exchange": {"path": jinfo.get("path", "columns" if world > 1 else None), "backend": backend if world > 1 else None,
+                       "exchange": {"path": jinfo.get("path", "columns" if world > 1 else None),
+                                    "backend": jinfo.get("backend", backend if world > 1 else None),
+                                    "order": jinfo.get("order"), "groups": jinfo.get("groups"), "left_slices": jinfo.get("left_slices"),
+                                    "forced_at_world_1": bool(force_exchange and world == 1),
                                     "sent_rows_rank0": jinfo.get("sent_rows", 0)},
                        "device": info["name"].strip()},
             "verified": verified, "rows_out": rows_out,
             "roofline": roofline,
+            "kernels": kernels,
+            "roofline_measured_traffic": measured,
+            "cold_first_step_ms": round(cold_first_step_ms, 1) if cold_first_step_ms is not None else None,
             "roofline_whole_join": {"bound": "hbm", "achieved": round(whole, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                     "frac": round(whole / HBM_PEAK_GBPS, 4),
                                     "note": "28 B per row-pair (SURVEY 8d) x rows/side / wall time per step, all GPUs"},
@@ -286,6 +337,7 @@ def main():
             print("VERIFICATION FAILED: output digest does not match the inputs", file=sys.stderr)
     if world > 1:
         dist.barrier()
+    if dist.is_initialized():
         dist.destroy_process_group()
     ctx.close()
     return 0 if verified else 1

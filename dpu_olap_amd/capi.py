@@ -28,7 +28,7 @@ EXPORTS = [
     "olap_set_stream", "olap_get_stream", "olap_synchronize", "olap_reserve_workspace",
     "olap_workspace_bytes", "olap_malloc", "olap_free", "olap_memcpy_h2d", "olap_memcpy_d2h",
     "olap_memset", "olap_set_profiling", "olap_reset_timers", "olap_get_timers", "olap_filter_lt",
-    "olap_sum", "olap_take", "olap_partition_u32", "olap_partition_tuples_u32", "olap_split_tuples_u32", "olap_join_u32", "olap_join_tuples_u32", "olap_join_presplit_u32", "olap_join_set_right_ready_event", "olap_join_set_unmatched", "olap_join_configure", "olap_join_set_hash_skip_bits", "olap_set_tuning", "olap_get_counter",
+    "olap_sum", "olap_take", "olap_partition_u32", "olap_partition_tuples_u32", "olap_split_tuples_u32", "olap_join_u32", "olap_join_tuples_u32", "olap_join_presplit_u32", "olap_join_set_right_ready_event", "olap_join_set_unmatched", "olap_join_configure", "olap_join_set_hash_skip_bits", "olap_set_tuning", "olap_get_counter", "olap_phase_kernel",
     "olap_gen_uniform_u32", "olap_gen_uniform_u64", "olap_gen_index_u32", "olap_gen_fk_u32",
     "olap_gen_uniform_u32_at", "olap_checksum", "olap_checksum_rows3_u32",
 ]
@@ -142,6 +142,7 @@ def load_library(path: str | None = None) -> C.CDLL:
         "olap_join_set_hash_skip_bits": (i, [vp, i]),
         "olap_set_tuning": (i, [vp, C.c_char_p, i]),
         "olap_get_counter": (i, [vp, C.c_char_p, C.POINTER(C.c_uint64)]),
+        "olap_phase_kernel": (C.c_char_p, [vp, C.c_char_p]),
         "olap_gen_uniform_u32": (i, [vp, vp, u64, u64, u32, u64]),
         "olap_gen_uniform_u64": (i, [vp, vp, u64, u64, u32, u64]),
         "olap_gen_index_u32": (i, [vp, vp, u64, u32]),
@@ -355,6 +356,11 @@ class Context:
 
     def set_tuning(self, key: str, value: int):
         self._check(self.lib.olap_set_tuning(self.h, key.encode(), value))
+
+    def phase_kernel(self, phase: str) -> str:
+        """rocprofv3 name of the kernel last launched under a timer phase ("" if none)."""
+        r = self.lib.olap_phase_kernel(self.h, phase.encode())
+        return r.decode() if r else ""
 
     def get_counter(self, name: str) -> int:
         """Diagnostics of the last join: "join_attempts", "join_region_overflows"."""

@@ -88,8 +88,14 @@ int import_column(olap_ctx* ctx, const struct ArrowArray* const* batches, uint64
     if (!a || !a->release) return ctx->fail(OLAP_ERR_INVALID, "batch %llu is null or released", (unsigned long long)b);
     if (a->n_buffers != 2 || a->n_children != 0 || a->dictionary)
       return ctx->fail(OLAP_ERR_INVALID, "batch %llu is not a primitive array", (unsigned long long)b);
-    if (a->null_count > 0) return ctx->fail(OLAP_ERR_INVALID, "batch %llu has nulls: the path is defined on non-nullable columns", (unsigned long long)b);
     if (a->length < 0 || a->offset < 0) return ctx->fail(OLAP_ERR_INVALID, "batch %llu has a negative length or offset", (unsigned long long)b);
+    int64_t nulls = a->null_count;
+    if (nulls < 0 && a->buffers[0]) {  // -1 = "not computed" (legal in the C Data Interface): count the cleared validity bits
+      const uint8_t* bits = static_cast<const uint8_t*>(a->buffers[0]);
+      nulls = 0;
+      for (int64_t i = a->offset; i < a->offset + a->length; ++i) nulls += !((bits[i >> 3] >> (i & 7)) & 1);
+    }
+    if (nulls > 0) return ctx->fail(OLAP_ERR_INVALID, "batch %llu has nulls: the path is defined on non-nullable columns", (unsigned long long)b);
     if (a->length && !a->buffers[1]) return ctx->fail(OLAP_ERR_INVALID, "batch %llu has no data buffer", (unsigned long long)b);
     (*ptrs)[b] = a->length ? static_cast<const char*>(a->buffers[1]) + a->offset * width : nullptr;
     (*rows)[b] = (uint64_t)a->length;

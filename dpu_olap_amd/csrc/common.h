@@ -75,6 +75,7 @@ struct olap_ctx {
     hipEvent_t a, b;
   };
   std::vector<Pending> pending;
+  std::string phase_kernel[olap::PH_COUNT];  // name of the kernel last launched under each phase, as rocprofv3 prints it
   std::vector<hipEvent_t> event_pool;
 
   std::unordered_set<const void*> lds_raised;  // kernels whose dynamic-LDS limit was raised on this device
@@ -89,6 +90,7 @@ struct olap_ctx {
   int wc_geometry = 2;     // 2: passes of <= 512 buckets use 512-thread workgroups on 4096-tuple tiles, two per CU
   int capacity_mode = 1;   // last radix pass without histogram (fixed-capacity regions + exact fallback)
   int ring_scatter = 3;    // bit 0: claiming pass, bit 1: capacity pass: passes of <= 512 buckets run the ring scatter (ring_scatter.h): 128-byte lines, one workgroup per CU
+  int ring_interleave = 0; // ring scatter from columns: tiles dealt to the workgroups round-robin in chunks of this many (0: one contiguous run each)
   int ring_tpt = 8;        // tuples per producer thread and tile of the ring scatter (8: 4096-tuple tiles, 4: 2048)
   int claim_mode = 1;      // pass 0 of a two-pass plan without histogram (claimed allotments): 0 off, 1 auto, 2 always
   int hash_skip_bits = 0;  // top hash bits already fixed by an upstream owner split
@@ -277,6 +279,21 @@ __device__ __forceinline__ uint4 gload4(const void* p) {
 __device__ __forceinline__ uint2 gload2(const void* p) {
   const u32x2_t v = *(const OLAP_GLOBAL u32x2_t*)p;
   return make_uint2(v.x, v.y);
+}
+// streaming variants (read once / written once): the `nt` cache policy
+__device__ __forceinline__ uint4 gload4_nt(const void* p) {
+  const u32x4_t v = __builtin_nontemporal_load((const OLAP_GLOBAL u32x4_t*)p);
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void gstore4(void* p, uint4 v) {
+  u32x4_t t;
+  t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+  *(OLAP_GLOBAL u32x4_t*)p = t;
+}
+__device__ __forceinline__ void gstore4_nt(void* p, uint4 v) {
+  u32x4_t t;
+  t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+  __builtin_nontemporal_store(t, (OLAP_GLOBAL u32x4_t*)p);
 }
 __device__ __forceinline__ void gstore2(void* p, uint2 v) {
   u32x2_t t;

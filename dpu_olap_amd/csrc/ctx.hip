@@ -344,6 +344,13 @@ int olap_memset(olap_ctx* ctx, void* dst, int byte_value, uint64_t bytes) {
   return OLAP_OK;
 }
 
+const char* olap_phase_kernel(olap_ctx* ctx, const char* phase_name) {
+  if (!ctx || !phase_name) return "";
+  for (int p = 0; p < PH_COUNT; ++p)
+    if (!std::strcmp(kPhaseNames[p], phase_name)) return ctx->phase_kernel[p].c_str();
+  return "";
+}
+
 int olap_set_profiling(olap_ctx* ctx, int enabled) {
   if (!ctx) return OLAP_ERR_INVALID;
   ctx->profiling = enabled != 0;

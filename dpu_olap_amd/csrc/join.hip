@@ -115,9 +115,15 @@ struct SideOut {
   uint64_t* dense = nullptr; // capacity layout: [P]
 };
 
+// Region size of the capacity layout: the average partition plus the larger of 1/8 and six standard deviations of a
+// partition whose keys repeat like a Poisson(1) foreign key (variance 2 * avg) -- the second term matters for small
+// partitions (avg 512: 4 sigma = 128 was overrun by a few of 2^16 partitions on uniform data).
 static uint32_t region_cap(uint64_t rows, uint64_t P) {
   const uint64_t avg = (rows + P - 1) / P;
-  return (uint32_t)align_up(avg + avg / 8 + 64, kLineAlign);
+  uint64_t sd = 1;
+  while (sd * sd < 2 * avg) ++sd;
+  const uint64_t slack = avg / 8 > 6 * sd ? avg / 8 : 6 * sd;
+  return (uint32_t)align_up(avg + slack + 64, kLineAlign);
 }
 
 // The last pass may skip its histogram (capacity layout) when every workgroup owns whole
@@ -188,6 +194,9 @@ static int launch_wc(olap_ctx* ctx, unsigned blocks, const PassSrc& src, uint32_
                      const uint64_t* seg_out, uint2* out, const CapOut& co) {
   constexpr uint32_t kLds = WcLds<LINE, BLOCK, TILE>::kBytes;
   OLAP_TRY(allow_lds(ctx, reinterpret_cast<const void*>(k_part_scatter_wc<SRC, CAPM, LINE, BLOCK, TILE>), kLds));
+  char label[96];
+  std::snprintf(label, sizeof label, "olap::k_part_scatter_wc<%d, %s, %d, %d, %d>", SRC, CAPM ? "true" : "false", LINE, BLOCK, TILE);
+  ctx->phase_kernel[CAPM ? PH_PART_SCATTER_CAP : PH_PART_SCATTER] = label;
   hipLaunchKernelGGL((k_part_scatter_wc<SRC, CAPM, LINE, BLOCK, TILE>), dim3(blocks), dim3(BLOCK), kLds, ctx->stream, src, shift, fbits,
                      hist, seg_out, out, co);
   OLAP_HIP(ctx, hipGetLastError());
@@ -215,6 +224,9 @@ static int launch_claim_as(olap_ctx* ctx, unsigned blocks, const PassSrc& src, u
                            const ClaimOut& co) {
   constexpr uint32_t kLds = WcLds<8, BLOCK, TILE>::kBytes;
   OLAP_TRY(allow_lds(ctx, reinterpret_cast<const void*>(k_part_scatter_claim<SRC, BLOCK, TILE>), kLds));
+  char label[96];
+  std::snprintf(label, sizeof label, "olap::k_part_scatter_claim<%d, %d, %d>", SRC, BLOCK, TILE);
+  ctx->phase_kernel[PH_PART_SCATTER_CLAIM] = label;
   hipLaunchKernelGGL((k_part_scatter_claim<SRC, BLOCK, TILE>), dim3(blocks), dim3(BLOCK), kLds, ctx->stream, src, shift, fbits, out, co);
   OLAP_HIP(ctx, hipGetLastError());
   return OLAP_OK;
@@ -235,6 +247,10 @@ static int launch_ring_as(olap_ctx* ctx, unsigned blocks, const PassSrc& src, ui
   constexpr uint32_t kLds = RingCfg<kRingFmax, kRingLine, kRingBlock, kRingProd>::kBytes;
   auto kernel = k_part_scatter_ring<SRC, CLAIM, kRingFmax, kRingLine, kRingBlock, kRingProd, TPT>;
   OLAP_TRY(allow_lds(ctx, reinterpret_cast<const void*>(kernel), kLds));
+  char label[96];
+  std::snprintf(label, sizeof label, "olap::k_part_scatter_ring<%d, %s, %d, %d, %d, %d, %d>", SRC, CLAIM ? "true" : "false", kRingFmax, kRingLine,
+                kRingBlock, kRingProd, TPT);
+  ctx->phase_kernel[CLAIM ? PH_PART_SCATTER_CLAIM : PH_PART_SCATTER_CAP] = label;
   hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kRingBlock), kLds, ctx->stream, src, shift, fbits, out, co, cq);
   OLAP_HIP(ctx, hipGetLastError());
   return OLAP_OK;
@@ -354,6 +370,7 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
       if (nb == 0) nb = 1;
       src.tiles_per_block = (tiles + nb - 1) / nb;
       if (src.tiles_per_block == 0) src.tiles_per_block = 1;
+      src.interleave = ring_claim ? (uint32_t)ctx->ring_interleave : 0u;
       blocks = (tiles + src.tiles_per_block - 1) / src.tiles_per_block;
       if (blocks == 0) blocks = 1;
       bseg = blocks;
@@ -481,7 +498,7 @@ struct JoinIn {
 
 static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t* out_y, uint32_t* out_x, int out_mem,
                      uint64_t NL, uint64_t NR, uint32_t total_bits, bool allow_capacity, olap_join_stats* st,
-                     unsigned long long counters[5], uint64_t* rows_out) {
+                     unsigned long long counters[6], uint64_t* rows_out, hipEvent_t right_ready) {
   const uint32_t* const* lfk = in.lfk;
   const uint32_t* const* ly = in.ly;
   const uint32_t* const* rpk = in.rpk;
@@ -535,7 +552,7 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
   uint2* tmp1 = plan.passes >= 3 ? (uint2*)ws_alloc(ctx, (maxN + 2) * 8) : nullptr;
   uint2* Lt = (uint2*)ws_alloc(ctx, (lt_tuples + 2) * 8);
   uint2* Rt = (uint2*)ws_alloc(ctx, (rt_tuples + 2) * 8);
-  unsigned long long* d_cnt = (unsigned long long*)ws_alloc(ctx, 40);
+  unsigned long long* d_cnt = (unsigned long long*)ws_alloc(ctx, 48);
   uint32_t *d_fk = out_fk, *d_y = out_y, *d_x = out_x;
   if (out_mem == OLAP_MEM_HOST) {
     d_fk = (uint32_t*)ws_alloc(ctx, NL * 4 + 4);
@@ -544,7 +561,7 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
   }
   if ((plan.passes >= 2 && !tmp0) || (plan.passes >= 3 && !tmp1) || !Lt || !Rt || !d_cnt || !d_fk || !d_y || !d_x)
     return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (join buffers)");
-  OLAP_HIP(ctx, hipMemsetAsync(d_cnt, 0, 40, ctx->stream));
+  OLAP_HIP(ctx, hipMemsetAsync(d_cnt, 0, 48, ctx->stream));
   uint32_t* miss_bits = nullptr;  // inner-join mode: one bit per output row, set where the probe missed
   if (drop) {
     miss_bits = (uint32_t*)ws_alloc(ctx, miss_words * 4);
@@ -554,9 +571,8 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
   SideOut lso, rso;
   OLAP_TRY(partition_side(ctx, lcs, l_pay, in.l_tuples, NL, plan, (uint32_t)ctx->hash_skip_bits, tmp0, tmp1, Lt, lcap,
                           d_cnt + 4, &lso, in.l_pre, lclaim));
-  if (ctx->right_ready) {  // the right table may still be arriving (olap_join_set_right_ready_event)
-    OLAP_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->right_ready, 0));
-    ctx->right_ready = nullptr;
+  if (right_ready) {  // the right table may still be arriving (olap_join_set_right_ready_event)
+    OLAP_HIP(ctx, hipStreamWaitEvent(ctx->stream, right_ready, 0));
   }
   OLAP_TRY(partition_side(ctx, rcs, r_pay, in.r_tuples, NR, plan, (uint32_t)ctx->hash_skip_bits, tmp0, tmp1, Rt, rcap,
                           d_cnt + 4, &rso, in.r_pre, rclaim));
@@ -568,19 +584,23 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
     const PartView lv{Lt, lso.off, lso.cnt, lso.dense, lso.cap};
     const uintptr_t a_fk = (uintptr_t)d_fk & 7, a_y = (uintptr_t)d_y & 7, a_x = (uintptr_t)d_x & 7;
     const uint32_t pair_ok = (a_fk | a_y | a_x) == 0 ? 1u : (a_fk == 4 && a_y == 4 && a_x == 4) ? 2u : 0u;
+    ctx->phase_kernel[PH_JOIN_PROBE] = direct ? "olap::k_join_probe_direct" : "olap::k_join_probe";
     if (direct) {
       uint64_t dgrid = (uint64_t)ctx->compute_units * 8;
       if (dgrid > P) dgrid = P;
       hipLaunchKernelGGL(k_join_probe_direct, dim3((unsigned)dgrid), dim3(kDBlock), 0, ctx->stream, rv, lv, P, table_bits,
-                         d_fk, d_y, d_x, pair_ok, d_cnt, miss_bits);
+                         (uint32_t)ctx->hash_skip_bits, d_fk, d_y, d_x, pair_ok, d_cnt, miss_bits);
     } else {
       hipLaunchKernelGGL(k_join_probe, dim3((unsigned)grid), dim3(kJBlock), 0, ctx->stream, rv, lv, P, d_fk, d_y, d_x,
                          pair_ok, d_cnt, miss_bits);
     }
     OLAP_HIP(ctx, hipGetLastError());
   }
-  OLAP_HIP(ctx, hipMemcpyAsync(counters, d_cnt, 40, hipMemcpyDeviceToHost, ctx->stream));
+  OLAP_HIP(ctx, hipMemcpyAsync(counters, d_cnt, 48, hipMemcpyDeviceToHost, ctx->stream));
   OLAP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (counters[5] && counters[2] == 0 && counters[4] == 0)
+    return ctx->fail(OLAP_ERR_INVALID, "%llu tuple(s) do not share the %d leading hash bits this join was told are fixed "
+                     "(olap_join_set_hash_skip_bits): the inputs were not split by owner", counters[5], ctx->hash_skip_bits);
   const bool sound = counters[2] == 0 && counters[4] == 0;  // no table / region overflow: the rows written are final
   uint64_t kept_rows = NL;
   if (drop && sound && counters[0]) {
@@ -658,6 +678,10 @@ static int join_run(olap_ctx* ctx, const JoinIn& jin, uint64_t NL, uint64_t NR, 
                     uint32_t* out_x, uint64_t out_capacity, int out_mem, uint64_t* out_rows, olap_join_stats* stats) {
   if (stats) std::memset(stats, 0, sizeof *stats);
   *out_rows = 0;
+  // one-shot: consumed here, so that EVERY way out of this call (empty sides, capacity errors, failures) drops it and a
+  // later join never waits on a stale handle
+  const hipEvent_t right_ready = ctx->right_ready;
+  ctx->right_ready = nullptr;
   if (NL == 0) return OLAP_OK;
   if (NL > out_capacity) return ctx->fail(OLAP_ERR_CAPACITY, "output capacity %llu < %llu left rows",
                                           (unsigned long long)out_capacity, (unsigned long long)NL);
@@ -679,14 +703,15 @@ static int join_run(olap_ctx* ctx, const JoinIn& jin, uint64_t NL, uint64_t NR, 
     if (ctx->direct_table && dbits >= 1 && dbits < (int)bits && (NR >> dbits) >= 2048) bits = (uint32_t)dbits;
   }
   if (jin.l_pre && bits <= jin.l_pre->bits) bits = jin.l_pre->bits + 1;  // at least one pass gathers the chunks
-  unsigned long long counters[5] = {0, 0, 0, 0, 0};
+  unsigned long long counters[6] = {0, 0, 0, 0, 0};
   uint64_t kept_rows = NL;
   bool allow_capacity = true;
   ctx->last_join_attempts = 0;
   ctx->last_join_region_overflows = 0;
   for (int attempt = 0; attempt < 4; ++attempt) {
     ++ctx->last_join_attempts;
-    OLAP_TRY(join_once(ctx, jin, out_fk, out_y, out_x, out_mem, NL, NR, bits, allow_capacity, stats, counters, &kept_rows));
+    OLAP_TRY(join_once(ctx, jin, out_fk, out_y, out_x, out_mem, NL, NR, bits, allow_capacity, stats, counters, &kept_rows,
+                       attempt == 0 ? right_ready : nullptr));
     if (attempt == 0) ctx->last_join_region_overflows = counters[4];
     if (counters[4]) {  // a fixed-capacity region overflowed (skew): redo with exact partitioning
       allow_capacity = false;
@@ -742,6 +767,11 @@ int olap_set_tuning(olap_ctx* ctx, const char* key, int value) {
   if (!std::strcmp(key, "ring_scatter")) {
     if (value < 0 || value > 3) return ctx->fail(OLAP_ERR_INVALID, "ring_scatter must be 0 (off), 1 (claiming pass), 2 (capacity pass) or 3 (both)");
     ctx->ring_scatter = value;
+    return OLAP_OK;
+  }
+  if (!std::strcmp(key, "ring_interleave")) {
+    if (value < 0 || value > 4096) return ctx->fail(OLAP_ERR_INVALID, "ring_interleave must be in [0, 4096]");
+    ctx->ring_interleave = value;
     return OLAP_OK;
   }
   if (!std::strcmp(key, "ring_tpt")) {

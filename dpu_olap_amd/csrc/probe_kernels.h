@@ -11,7 +11,8 @@ namespace olap {
 
 // ------------------------------------------------------------ build + probe
 // counters: [0] missing keys, [1] duplicate build keys, [2] overflowing
-// partitions, [3] max build rows
+// partitions, [3] max build rows, [4] region overflows (radix passes), [5] tuples whose
+// leading (skipped) hash bits differ from their partition's (direct table only)
 // A partitioned side: exact layout (cap == 0: partition p = [off[p], off[p+1])) or
 // capacity layout (partition p = [p * cap, p * cap + cnt[p]), dense start dense[p]).
 struct PartView {
@@ -187,8 +188,12 @@ constexpr int kDBlock = 512;
 // top bits + same low bits = same hash = same key), so a slot holds the payload and one
 // occupancy bit.  64 KiB values + 2 KiB bitmap: two workgroups of 512 per CU, and only the
 // bitmap needs clearing between partitions.
+// skip_bits > 0 (olap_join_set_hash_skip_bits: an upstream owner split fixed the leading hash bits): the slot of a
+// key is only its identity if every tuple of the partition shares those leading bits.  That precondition is CHECKED:
+// tuples whose leading bits differ from the partition's first build tuple are counted in counters[5] and the join
+// fails with OLAP_ERR_INVALID instead of returning the x of another key.
 __global__ __launch_bounds__(kDBlock, 4) void k_join_probe_direct(PartView RV, PartView LV, uint32_t nparts,
-                                                               uint32_t table_bits, uint32_t* out_fk,
+                                                               uint32_t table_bits, uint32_t skip_bits, uint32_t* out_fk,
                                                                uint32_t* out_y, uint32_t* out_x,
                                                                uint32_t pair_store_ok, unsigned long long* counters,
                                                                uint32_t* miss_bits) {
@@ -197,8 +202,9 @@ __global__ __launch_bounds__(kDBlock, 4) void k_join_probe_direct(PartView RV, P
   const uint2* R = RV.t;
   const uint2* L = LV.t;
   const uint32_t slots = 1u << table_bits, smask = slots - 1;
-  uint32_t my_miss = 0, my_dup = 0;
+  uint32_t my_miss = 0, my_dup = 0, my_foreign = 0;
   uint64_t my_max = 0;
+  const uint32_t top_shift = skip_bits ? 32u - skip_bits : 0u;
   for (uint32_t p = blockIdx.x; p < nparts; p += gridDim.x) {
     const uint64_t rlo = RV.cap ? (uint64_t)p * RV.cap : RV.off[p];
     const uint64_t rhi = RV.cap ? rlo + RV.cnt[p] : RV.off[p + 1];
@@ -211,6 +217,7 @@ __global__ __launch_bounds__(kDBlock, 4) void k_join_probe_direct(PartView RV, P
     const uint32_t pair_store = pair_store_ok && ((delta + (pair_store_ok >> 1)) & 1) == 0;
     if (n_r > my_max) my_max = n_r;
     if (n_l == 0) continue;
+    const uint32_t top_ref = (skip_bits && n_r) ? wang_hash(R[rlo].x) >> top_shift : 0u;  // leading bits every tuple here must share
     for (uint32_t i = threadIdx.x; i < (slots + 31) / 32; i += kDBlock) s_used[i] = 0;
     __syncthreads();
     {  // build
@@ -237,7 +244,9 @@ __global__ __launch_bounds__(kDBlock, 4) void k_join_probe_direct(PartView RV, P
           for (int h = 0; h < 2; ++h) {
             const uint32_t k = h ? v[u].z : v[u].x, val = h ? v[u].w : v[u].y;
             if (i0 + h < rlo || i0 + h >= rhi) continue;
-            const uint32_t slot = wang_hash(k) & smask;
+            const uint32_t hk = wang_hash(k);
+            if (skip_bits && (hk >> top_shift) != top_ref) ++my_foreign;
+            const uint32_t slot = hk & smask;
             const uint32_t bit = 1u << (slot & 31);
             if (atomicOr(&s_used[slot >> 5], bit) & bit) ++my_dup;  // equal key overwrites (hashtable.c:133)
             s_vals[slot] = val;
@@ -273,7 +282,9 @@ __global__ __launch_bounds__(kDBlock, 4) void k_join_probe_direct(PartView RV, P
             const uint32_t k = h ? v[u].z : v[u].x;
             ok[h] = i0 + h >= llo && i0 + h < lhi;
             if (!ok[h]) continue;
-            const uint32_t slot = wang_hash(k) & smask;
+            const uint32_t hk = wang_hash(k);
+            if (skip_bits && n_r && (hk >> top_shift) != top_ref) ++my_foreign;
+            const uint32_t slot = hk & smask;
             const bool hit = (s_used[slot >> 5] >> (slot & 31)) & 1u;
             xs[h] = s_vals[slot];
             if (!hit) {
@@ -305,9 +316,11 @@ __global__ __launch_bounds__(kDBlock, 4) void k_join_probe_direct(PartView RV, P
   }
   const uint64_t wm = wave_reduce_add((uint64_t)my_miss);
   const uint64_t wd = wave_reduce_add((uint64_t)my_dup);
+  const uint64_t wf = wave_reduce_add((uint64_t)my_foreign);
   if (lane_id() == 0) {
     if (wm) atomicAdd(&counters[0], (unsigned long long)wm);
     if (wd) atomicAdd(&counters[1], (unsigned long long)wd);
+    if (wf) atomicAdd(&counters[5], (unsigned long long)wf);
   }
   if (threadIdx.x == 0) atomicMax(&counters[3], (unsigned long long)my_max);
 }

@@ -38,6 +38,7 @@ struct PassSrc {
   const void* const* key_ptrs;
   const void* const* pay_ptrs;  // may be null: payload = global row index
   uint64_t tiles_per_block;
+  uint32_t interleave;  // ring scatter: workgroup w takes tiles w, w + grid, w + 2 grid, ... (0: a contiguous run of tiles_per_block)
   // SRC_TUPLES
   const uint2* tuples;
   const uint64_t* seg_off;  // [n_seg + 1]
@@ -135,7 +136,13 @@ struct ColsCursor {
 };
 
 // Loads one tile: kPTile / BLOCK tuples per thread, valid bits in the returned mask.
-template <int SRC, int BLOCK, bool WANT_PAYLOAD, int TILE = kPTile>
+#ifndef OLAP_RING_NT_LOAD
+#define OLAP_RING_NT_LOAD 0   // A/B builds (scripts/build_variant.sh): streaming `nt` loads in the ring scatter's producers
+#endif
+#ifndef OLAP_RING_NT_STORE
+#define OLAP_RING_NT_STORE 0  // ... `nt` stores for its output lines
+#endif
+template <int SRC, int BLOCK, bool WANT_PAYLOAD, int TILE = kPTile, bool NT = false>
 __device__ __forceinline__ uint32_t load_tile(const PassSrc& s, const TileRange& r, uint64_t tile, ColsCursor& cur,
                                               uint32_t (&key)[TILE / BLOCK], uint32_t (&pay)[TILE / BLOCK]) {
   constexpr int TPT = TILE / BLOCK;
@@ -170,10 +177,10 @@ __device__ __forceinline__ uint32_t load_tile(const PassSrc& s, const TileRange&
     if (fast) {
       uint4 kv[TPT / 4], pv[TPT / 4];
 #pragma unroll
-      for (int j = 0; j < TPT / 4; ++j) kv[j] = gload4((const uint4*)kp + j * BLOCK + threadIdx.x);
+      for (int j = 0; j < TPT / 4; ++j) kv[j] = NT ? gload4_nt((const uint4*)kp + j * BLOCK + threadIdx.x) : gload4((const uint4*)kp + j * BLOCK + threadIdx.x);
       if (WANT_PAYLOAD && pp) {
 #pragma unroll
-        for (int j = 0; j < TPT / 4; ++j) pv[j] = gload4((const uint4*)pp + j * BLOCK + threadIdx.x);
+        for (int j = 0; j < TPT / 4; ++j) pv[j] = NT ? gload4_nt((const uint4*)pp + j * BLOCK + threadIdx.x) : gload4((const uint4*)pp + j * BLOCK + threadIdx.x);
       }
 #pragma unroll
       for (int j = 0; j < TPT / 4; ++j) {
@@ -216,7 +223,7 @@ __device__ __forceinline__ uint32_t load_tile(const PassSrc& s, const TileRange&
       const uint4* tv = (const uint4*)(s.tuples + base);
 #pragma unroll
       for (int j = 0; j < TPT / 2; ++j) {
-        const uint4 t = tv[j * BLOCK + threadIdx.x];
+        const uint4 t = NT ? gload4_nt(tv + j * BLOCK + threadIdx.x) : tv[j * BLOCK + threadIdx.x];
         key[2 * j] = t.x;
         pay[2 * j] = t.y;
         key[2 * j + 1] = t.z;
@@ -672,7 +679,10 @@ struct ClaimOut {
   uint32_t* cursor;  // [n_seg * F], zeroed before the launch: tuples claimed per region
   unsigned long long* overflow;
 };
-constexpr uint32_t kClaimChunk = 128;
+#ifndef OLAP_CLAIM_CHUNK
+#define OLAP_CLAIM_CHUNK 128
+#endif
+constexpr uint32_t kClaimChunk = OLAP_CLAIM_CHUNK;  // tuples per claimed allotment (a multiple of 16)
 
 template <int SRC, int BLOCK, int TILE>
 __global__ __launch_bounds__(BLOCK) void k_part_scatter_claim(PassSrc s, uint32_t shift, uint32_t fbits, uint2* out,

@@ -82,7 +82,20 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring(PassSrc s, uint32_t
   uint32_t* want = (uint32_t*)(smem + C::kWant);
   const uint32_t F = 1u << fbits;
   const uint32_t kRing = (uint32_t)(FMAX * C::kRingMin) >> fbits;  // tuples per bucket ring (a power of two >= 2 * LINE)
-  const TileRange r = block_tiles<SRC, TILE>(s);
+  TileRange r = block_tiles<SRC, TILE>(s);
+  // Column input, interleaved: at any moment the workgroups read neighbouring tiles -- one contiguous window of each
+  // column that moves through it, spread over all HBM channels -- instead of 256 streams that start 64 MiB apart and
+  // advance in lockstep (every stream on the same channel at the same time).  tile_at(i) = i-th tile of this workgroup.
+  // s.interleave = N: the tiles are dealt in chunks of N consecutive tiles (a batch's pointers are looked up once per chunk).
+  const bool il = SRC == SRC_COLS && s.interleave != 0;
+  const uint64_t il_n = il ? s.interleave : 1, il_total = s.v.total_units;
+  if (il) {
+    const uint64_t chunks = (il_total + il_n - 1) / il_n;
+    r.t0 = 0;
+    r.t1 = chunks > blockIdx.x ? (chunks - blockIdx.x + gridDim.x - 1) / gridDim.x * il_n : 0;
+  }
+  auto tile_at = [&](uint64_t i) { return il ? ((i / il_n) * gridDim.x + blockIdx.x) * il_n + i % il_n : i; };
+  auto tile_ok = [&](uint64_t i) { return i < r.t1 && (!il || tile_at(i) < il_total); };
   if (CLAIM && r.t0 >= r.t1) return;  // nothing to read: claim nothing (uniform)
   const unsigned lane = lane_id();
   const unsigned wave = threadIdx.x / kWave;
@@ -116,8 +129,8 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring(PassSrc s, uint32_t
     A.mask = B.mask = Cc.mask = 0;
 #pragma unroll
     for (int i = 0; i < TPT; ++i) A.bk[i] = B.bk[i] = Cc.bk[i] = dummy;
-    if (r.t0 < r.t1) A.mask = load_tile<SRC, kProd, true, TILE>(s, r, r.t0, cur, A.key, A.pay);
-    if (r.t0 + 1 < r.t1) B.mask = load_tile<SRC, kProd, true, TILE>(s, r, r.t0 + 1, cur, B.key, B.pay);
+    if (tile_ok(r.t0)) A.mask = load_tile<SRC, kProd, true, TILE, OLAP_RING_NT_LOAD != 0>(s, r, tile_at(r.t0), cur, A.key, A.pay);
+    if (tile_ok(r.t0 + 1)) B.mask = load_tile<SRC, kProd, true, TILE, OLAP_RING_NT_LOAD != 0>(s, r, tile_at(r.t0 + 1), cur, B.key, B.pay);
     hash_tile(A);
     // CLAIM: thread t refills the reserve of bucket t
     const uint32_t tb = threadIdx.x;
@@ -161,7 +174,7 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring(PassSrc s, uint32_t
         }
       }
       n2.mask = 0;
-      if (tile + 2 < r.t1) n2.mask = load_tile<SRC, kProd, true, TILE>(s, r, tile + 2, cur, n2.key, n2.pay);
+      if (tile_ok(tile + 2)) n2.mask = load_tile<SRC, kProd, true, TILE, OLAP_RING_NT_LOAD != 0>(s, r, tile_at(tile + 2), cur, n2.key, n2.pay);
       __syncthreads();  // ---- barrier 2: complete lines are out, the rings have room again
       if (misc[0] == (uint32_t)tile + 1u) {  // some bucket was hot in this tile (uniform)
 #pragma unroll
@@ -244,7 +257,8 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring(PassSrc s, uint32_t
         if (j < n) {
           const uint2 e = list[j];
           const uint4 t = *(const uint4*)(ring + e.y + 2 * (lane % LPL));
-          ((uint4*)out)[(uint64_t)e.x * LPL + (lane % LPL)] = t;
+          if (OLAP_RING_NT_STORE) gstore4_nt((uint4*)out + (uint64_t)e.x * LPL + (lane % LPL), t);
+          else gstore4((uint4*)out + (uint64_t)e.x * LPL + (lane % LPL), t);
         }
       }
       __builtin_amdgcn_wave_barrier();

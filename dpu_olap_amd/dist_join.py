@@ -68,6 +68,21 @@ class GpuLocalOps:
     def empty(self, n: int) -> torch.Tensor:
         return torch.empty(max(n, 1), dtype=torch.int32, device=self.device)[:n]
 
+    # Columns that a kernel streams side by side (the {fk, y, x} result, a table's key and payload) should not sit an
+    # exact power of two apart: equal-sized columns allocated back to back do (16 GiB each at SF=2048), their row i
+    # then maps to the same HBM channel in every column and the streams collide.  column_skew_bytes > 0 carves the
+    # columns out of ONE allocation, column c shifted by (2c + 1) x column_skew_bytes + c x 4352 bytes.
+    column_skew_bytes = 1 << 20
+
+    def empty_columns(self, n: int, k: int):
+        """k int32 columns of n rows each."""
+        skew = int(self.column_skew_bytes)
+        if not skew or n == 0:
+            return tuple(self.empty(n) for _ in range(k))
+        off = lambda c: (c * ((n * 4 + 255) // 256 * 256) + ((2 * c + 1) * skew + c * 4352)) // 4
+        slab = torch.empty(off(k) + 4, dtype=torch.int32, device=self.device)
+        return tuple(slab[off(c):off(c) + n] for c in range(k))
+
     def partition(self, keys: Sequence[torch.Tensor], payload: Sequence[torch.Tensor], nr_partitions: int):
         rows = [int(k.numel()) for k in keys]
         n = sum(rows)
@@ -103,11 +118,11 @@ class GpuLocalOps:
 
     def empty_result(self, n: int):
         """The three result columns of this rank, filled group by group."""
-        return tuple(self.empty(n) for _ in range(3))
+        return self.empty_columns(n, 3)
 
     def join_tuples(self, lt: torch.Tensor, rt: torch.Tensor, skip_bits: int = 0):
         n = int(lt.numel())
-        out = [self.empty(n) for _ in range(3)]
+        out = self.empty_columns(n, 3)
         torch.cuda.current_stream(self.device).synchronize()  # inputs come from torch's stream; do not wait for RCCL's
         self.ctx.join_set_hash_skip_bits(skip_bits)
         try:
@@ -125,7 +140,7 @@ class GpuLocalOps:
         right table is still arriving."""
         l_ptr, l_span, l_lo, l_hi, n = self._span(lt, l_lo, l_hi)
         r_ptr, r_span, r_lo, r_hi, _ = self._span(rt, r_lo, r_hi)
-        out = list(out) if out is not None else [self.empty(n) for _ in range(3)]   # out: slices of empty_result()
+        out = list(out) if out is not None else list(self.empty_columns(n, 3))   # out: slices of empty_result()
         if right_ready is None:
             torch.cuda.current_stream(self.device).synchronize()  # inputs come from torch's stream; do not wait for RCCL's
         else:
@@ -172,7 +187,7 @@ class GpuLocalOps:
         if not len(left) or not len(right):           # (an empty ctypes table still has one slot)
             return self.join(left.keys, left.payloads, right.keys, right.payloads, skip_bits)
         n = sum(left.rows)
-        out = [self.empty(n) for _ in range(3)]
+        out = self.empty_columns(n, 3)
         torch.cuda.current_stream(self.device).synchronize()  # inputs come from torch's stream; do not wait for RCCL's
         self.ctx.join_set_hash_skip_bits(skip_bits)
         try:
@@ -187,7 +202,7 @@ class GpuLocalOps:
         lrows = [int(t.numel()) for t in lfk]
         rrows = [int(t.numel()) for t in rpk]
         n = sum(lrows)
-        out = [self.empty(n) for _ in range(3)]
+        out = self.empty_columns(n, 3)
         torch.cuda.current_stream(self.device).synchronize()  # inputs come from torch's stream; do not wait for RCCL's
         self.ctx.join_set_hash_skip_bits(skip_bits)
         try:
@@ -212,17 +227,25 @@ class _Pending:
         return self.recv
 
 
+def _pairwise_only(group) -> bool:
+    """gloo has no all_to_all_single on some builds: only THERE is the pairwise isend/irecv form used.  On RCCL
+    ("nccl") a failing collective is an error of the product path and is raised as such -- a silent
+    degradation would hide exactly the failure an 8-GPU run has to show."""
+    return dist.get_backend(group) == "gloo"
+
+
 def _exchange(send: torch.Tensor, in_splits, out_splits, empty, group, async_op: bool = False):
     """Personalised all-to-all of a 1-D tensor.  RCCL/NCCL: all_to_all_single (optionally
-    asynchronous, so it overlaps the partition kernels of the other table); backends
-    without it (gloo on some builds): pairwise isend/irecv."""
+    asynchronous, so it overlaps the partition kernels of the other table); gloo builds
+    without it: pairwise isend/irecv."""
     recv = empty(int(sum(out_splits)))
     try:
         work = dist.all_to_all_single(recv, send, output_split_sizes=list(out_splits), input_split_sizes=list(in_splits),
                                       group=group, async_op=async_op)
         return _Pending(recv, work) if async_op else recv
     except (RuntimeError, NotImplementedError):
-        pass
+        if not _pairwise_only(group):
+            raise
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     so = [0]
     for s in in_splits:
@@ -251,11 +274,13 @@ def _exchange_counts(cnt_in: torch.Tensor, world: int, group) -> torch.Tensor:
         dist.all_to_all_single(cnt_out, cnt_in, group=group)
         return cnt_out
     except (RuntimeError, NotImplementedError):
-        per = cnt_in.numel() // world
-        gathered = [torch.empty_like(cnt_in) for _ in range(world)]
-        dist.all_gather(gathered, cnt_in, group=group)
-        rank = dist.get_rank(group)
-        return torch.stack([gt.view(world, per)[rank] for gt in gathered]).view(-1)
+        if not _pairwise_only(group):
+            raise
+    per = cnt_in.numel() // world
+    gathered = [torch.empty_like(cnt_in) for _ in range(world)]
+    dist.all_gather(gathered, cnt_in, group=group)
+    rank = dist.get_rank(group)
+    return torch.stack([gt.view(world, per)[rank] for gt in gathered]).view(-1)
 
 
 FUSED_SPLIT_BITS = 9  # owner bits + sub-bucket bits of the fused split: one 512-bucket pass
@@ -273,30 +298,36 @@ def _chunk_tables(cnt: torch.Tensor):
 
 
 class _Shipped:
-    """One input slice of one table after the split, its K group exchanges in flight:
-    pend[g].wait() -> what this rank received for sub-bucket group g (sender-major, then low sub-bucket);
+    """One input slice of one table after the split.  ship(g) starts the all-to-all of sub-bucket group g;
+    pend[g].wait() -> what this rank received for group g (sender-major, then low sub-bucket);
     recv[q][g][l] = tuples sender q shipped for (group g, low sub-bucket l); sent[g][p], got[g][q] = message sizes."""
 
-    def __init__(self, pend, recv, sent, got):
-        self.pend, self.recv, self.sent, self.got = pend, recv, sent, got
+    def __init__(self, ops, t, off, recv, sent, got, world, L, group):
+        self.ops, self.t, self.off, self.recv, self.sent, self.got = ops, t, off, recv, sent, got
+        self.world, self.L, self.group = world, L, group
+        self.pend = [None] * len(sent)
+
+    def ship(self, g: int):
+        run = self.t[self.off[g * self.world * self.L]:self.off[(g + 1) * self.world * self.L]]   # everything group g sends, owner-major
+        self.pend[g] = _exchange(run, self.sent[g], self.got[g], self.ops.empty_tuples, self.group, async_op=True)
+
+    def ship_all(self):
+        for g in range(len(self.pend)):
+            self.ship(g)
+        return self
 
 
-def _split_and_ship(ops, keys, payload, world: int, gbits: int, lbits: int, group) -> _Shipped:
+def _split(ops, keys, payload, world: int, gbits: int, lbits: int, group) -> _Shipped:
     """Split one slice into world x K x L buckets (owner = top hash bits, then group, then low sub-bucket)
-    laid out group-major, and start one all-to-all per group."""
+    laid out group-major, and tell every owner how much it will receive (one small all-to-all)."""
     obits, K, L = world.bit_length() - 1, 1 << gbits, 1 << lbits
     t, off = ops.split_tuples(keys, payload, obits, gbits, lbits)          # bucket order (group, owner, low)
     cnt = torch.tensor([off[k + 1] - off[k] for k in range(K * world * L)], dtype=torch.int64).view(K, world, L)
     to_peers = cnt.permute(1, 0, 2).contiguous().view(-1)                 # per owner: its K x L counts
-    dev = t.device
-    recv = _exchange_counts(to_peers.to(dev), world, group).view(world, K, L).cpu()
+    recv = _exchange_counts(to_peers.to(t.device), world, group).view(world, K, L).cpu()
     sent = [[int(v) for v in cnt[g].sum(1)] for g in range(K)]
     got = [[int(v) for v in recv[:, g].sum(1)] for g in range(K)]
-    pend = []
-    for g in range(K):
-        run = t[off[g * world * L]:off[(g + 1) * world * L]]               # everything group g sends, owner-major
-        pend.append(_exchange(run, sent[g], got[g], ops.empty_tuples, group, async_op=True))
-    return _Shipped(pend, recv, sent, got)
+    return _Shipped(ops, t, off, recv, sent, got, world, L, group)
 
 
 def _group_tables(slices, g: int, world: int, L: int, width: int):
@@ -320,12 +351,17 @@ def distributed_join(ops, left_batches: Sequence, right_batches: Sequence, group
     """left_batches / right_batches: this rank's batches as (key, payload) tensor pairs.
     Returns (fk, y, x, info): this rank's shard of the join result (rows whose key it owns)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1 and isinstance(left_batches, DeviceBatches) and isinstance(right_batches, DeviceBatches) and hasattr(ops, "join_batches"):
+    # force_exchange: take the split -> all-to-all -> pre-split join route at world size 1 too (a process group of one
+    # rank), so that the exchange code runs -- through RCCL -- on a one-GPU box (tests/test_bench_multirank_gpu.py)
+    forced = world == 1 and dist.is_initialized() and getattr(ops, "force_exchange", False)
+    if forced:
+        pass
+    elif world == 1 and isinstance(left_batches, DeviceBatches) and isinstance(right_batches, DeviceBatches) and hasattr(ops, "join_batches"):
         fk, y, x, stats = ops.join_batches(left_batches, right_batches, 0)
         return fk, y, x, {"world": 1, "stats": stats, "sent_rows": 0}
     lfk, ly = [b[0] for b in left_batches], [b[1] for b in left_batches]
     rpk, rx = [b[0] for b in right_batches], [b[1] for b in right_batches]
-    if world == 1:
+    if world == 1 and not forced:
         fk, y, x, stats = ops.join(lfk, ly, rpk, rx, 0)
         return fk, y, x, {"world": 1, "stats": stats, "sent_rows": 0}
     if world & (world - 1):
@@ -343,11 +379,30 @@ def distributed_join(ops, left_batches: Sequence, right_batches: Sequence, group
         gbits, lbits = K.bit_length() - 1, (S // K).bit_length() - 1
         L = 1 << lbits
         t0 = time.perf_counter()
-        H = max(1, min(int(getattr(ops, "left_slices", 1)), len(lfk)))
+        # H is the SAME on every rank (a knob, not a function of this rank's batch count: every slice costs one
+        # count exchange + K all-to-alls, and all ranks must issue the same collectives); a rank with fewer
+        # batches than slices ships empty slices.
+        H = max(1, int(getattr(ops, "left_slices", 1)))
         cuts = [len(lfk) * h // H for h in range(H + 1)]
-        left = [_split_and_ship(ops, lfk[cuts[h]:cuts[h + 1]], ly[cuts[h]:cuts[h + 1]], world, gbits, lbits, group) for h in range(H)]
-        t1 = time.perf_counter()   # left table split, its exchanges in flight
-        right = _split_and_ship(ops, rpk, rx, world, gbits, lbits, group)
+        # Issue order of the 2-table x K-group exchanges (RCCL executes them in issue order):
+        #   "table": L slice 0 (all groups), L slice 1, ..., then R (all groups) -- the links start after 1/H of the
+        #            left split, but group 0 of R travels behind ALL of L;
+        #   "group": split everything first, then L g0, R g0, L g1, R g1, ... -- the join of group 0 can start after
+        #            2/K of the bytes have moved, at the price of idle links during the splits.
+        order = getattr(ops, "exchange_order", "table")
+        left = []
+        for h in range(H):
+            sh = _split(ops, lfk[cuts[h]:cuts[h + 1]], ly[cuts[h]:cuts[h + 1]], world, gbits, lbits, group)
+            left.append(sh.ship_all() if order == "table" else sh)
+        t1 = time.perf_counter()   # left table split (its exchanges in flight under "table")
+        right = _split(ops, rpk, rx, world, gbits, lbits, group)
+        if order == "table":
+            right.ship_all()
+        else:
+            for gi in range(K):
+                for sh in left:
+                    sh.ship(gi)
+                right.ship(gi)
         t2 = time.perf_counter()   # right table split, all exchanges issued
         overlap = getattr(ops, "overlap_right_exchange", False)
         n_left = [sum(sum(sh.got[gi]) for sh in left) for gi in range(K)]          # left rows this rank joins, per group
@@ -400,7 +455,8 @@ def distributed_join(ops, left_batches: Sequence, right_batches: Sequence, group
             for key, v in wall.items():
                 timers[key] = timers.get(key, 0.0) + v
         return fk, y, x, {"world": world, "stats": stats, "sent_rows": sent, "recv_left": recv_left, "recv_right": recv_right,
-                          "path": "fused", "groups": K, "left_slices": H, "wall_ms": wall}
+                          "path": "fused", "groups": K, "left_slices": H, "order": order, "wall_ms": wall,
+                          "backend": dist.get_backend(group)}
     if hasattr(ops, "partition_tuples"):
         # zipped path: one int64 tensor per table; the left table's exchange overlaps the
         # owner split of the right table (RCCL runs on its own stream)
@@ -431,6 +487,8 @@ def distributed_join(ops, left_batches: Sequence, right_batches: Sequence, group
     try:
         dist.all_to_all_single(cnt_out, cnt_in, group=group)
     except (RuntimeError, NotImplementedError):
+        if not _pairwise_only(group):
+            raise
         gathered = [torch.empty_like(cnt_in) for _ in range(world)]
         dist.all_gather(gathered, cnt_in, group=group)
         rank = dist.get_rank(group)

@@ -240,18 +240,28 @@ class PartitionGpu(_Op):
                 self.payload = None
         self.nr_partitions = nr_partitions
 
+    @staticmethod
+    def _u32_batches(cols):
+        """Host batches as contiguous uint32 arrays (the reference's only element type, dpu/shared/kernels/common.h:3);
+        the returned list owns whatever had to be copied."""
+        return [c if isinstance(c, DeviceArray) else np.ascontiguousarray(c).astype(np.uint32, copy=False) for c in cols]
+
     def Run(self) -> list:
         self._need_prepare()
-        kp, rows, mem, _ = _table([k if isinstance(k, DeviceArray) else k.astype(np.uint32, copy=False) for k in self.keys])
+        # the uint32 views / copies the pointer tables point into must outlive the C call: _table() returns bare
+        # addresses (int32 / int64 host batches are COPIED by the conversion)
+        keys = self._u32_batches(self.keys)
+        payload = self._u32_batches(self.payload) if self.payload is not None else None
+        kp, rows, mem, _ = _table(keys)
         pp = None
-        if self.payload is not None:
-            pp, _, pmem, _ = _table([p if isinstance(p, DeviceArray) else p.astype(np.uint32, copy=False) for p in self.payload])
-            if self.keys and pmem != mem:
+        if payload is not None:
+            pp, _, pmem, _ = _table(payload)
+            if keys and pmem != mem:
                 raise ValueError("key and payload batches must live in the same memory space")
         n = int(sum(rows))
         ok = np.empty(max(n, 1), dtype=np.uint32)
         op = np.empty(max(n, 1), dtype=np.uint32)
-        self._keep = (self.keys, self.payload)
+        self._keep = (keys, payload)
         if mem == capi.MEM_DEVICE:
             dk, dp = self.system_.empty(n, "uint32"), self.system_.empty(n, "uint32")
             offs = self.system_.partition_u32(kp, pp, rows, mem, self.nr_partitions, dk.ptr, dp.ptr, n, capi.MEM_DEVICE)

@@ -106,6 +106,11 @@ int olap_reset_timers(olap_ctx* ctx);
 int olap_get_timers(olap_ctx* ctx, const char** names, double* total_ms, uint64_t* launches,
                     int cap, int* out_n);
 
+/* Name of the kernel last launched under a phase of olap_get_timers, spelled as rocprofv3 --kernel-trace prints it
+ * (e.g. "olap::k_part_scatter_ring<0, true, 512, 16, 1024, 8, 8>"), so a bench line can be matched against a
+ * profile; "" for phases that are not a single kernel.  Static storage of the context. */
+const char* olap_phase_kernel(olap_ctx* ctx, const char* phase_name);
+
 /* ------------------------------------------------------------------ filter
  * Replaces kernel_filter (dpu/shared/kernels/filter.c:57-177, predicate :25) and
  * FilterDpu::GetResult's per-DPU result pull (host/filter/filter_dpu.cc:50-101).

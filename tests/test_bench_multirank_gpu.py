@@ -40,6 +40,28 @@ def test_bench_multirank_on_one_gpu(world, sf):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("order", ["table", "group"])
+def test_bench_exchange_path_over_rccl_at_world_size_one(order):
+    """The multi-GPU route of bench.py -- fused split -> all_to_all_single over RCCL ("nccl") -> olap_join_presplit_u32
+    per sub-bucket group -- executed on the ONE GPU of a gpurun box: a process group of one rank
+    (init_process_group("nccl", device_id=...)), forced with --force-exchange.  A failing RCCL call is an error here
+    (dist_join falls back to pairwise isend/irecv on gloo only).  SF=16, digest verified."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--sf", "16",
+           "--no-cpu-baseline", "--force-exchange", "--exchange-order", order]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    ex = d["config"]["exchange"]
+    assert d["verified"] and d["rows_out"] == 16 * (2 << 20)
+    assert ex["backend"] == "nccl" and ex["path"] == "fused" and ex["forced_at_world_1"] and ex["order"] == order
+    assert ex["groups"] == 4 and ex["left_slices"] == 2
+    assert d["config"]["radix"]["missing_keys"] == 0 and "rank0_wall_ms_per_step" in d
+
+
+@pytest.mark.gpu
 def test_bench_ops_two_ranks_on_one_gpu():
     """filter / sum / take shard by batch with no data-path communication: two ranks
     share cuda:0, meet only for the barrier, the max time and the final add; results verified

@@ -106,3 +106,44 @@ def test_operator_argument_plumbing_without_gpu():
     import pyarrow as pa
     rb = pa.record_batch({"fk": pa.array([1, 2], pa.uint32()), "y": pa.array([3, 4], pa.uint32())})
     assert ops._columns([rb], 1)[0].tolist() == [3, 4]
+
+
+def test_partition_operator_keeps_converted_batches_alive():
+    """PartitionGpu.Run hands the C ABI bare addresses; when a host batch had to be converted to uint32 (int32 /
+    int64 input) the converted copy must be referenced until the call returns.  Checked on CPU with a stand-in
+    Device whose partition_u32 reads the memory behind the pointer tables, after a garbage collection."""
+    import ctypes
+    import gc
+
+    import numpy as np
+
+    import oracle
+    from dpu_olap_amd import capi, operators
+
+    class FakeDevice:
+        def set_profiling(self, on): pass
+        def reset_timers(self): pass
+
+        def partition_u32(self, kp, pp, rows, mem, P, out_k, out_p, n, out_mem):
+            gc.collect()
+            junk = [np.full(70001, 0xDEADBEEF, dtype=np.uint32) for _ in range(8)]   # reuse freed blocks, if any
+            ks = np.concatenate([np.ctypeslib.as_array(ctypes.cast(int(kp[b]), ctypes.POINTER(ctypes.c_uint32)), (int(rows[b]),)).copy()
+                                 for b in range(len(rows))])
+            ps = np.concatenate([np.ctypeslib.as_array(ctypes.cast(int(pp[b]), ctypes.POINTER(ctypes.c_uint32)), (int(rows[b]),)).copy()
+                                 for b in range(len(rows))])
+            del junk
+            ok, orow, hist = oracle.partition(ks, P)
+            ctypes.memmove(out_k, ok.ctypes.data, ok.nbytes)
+            op = ps[orow]
+            ctypes.memmove(out_p, op.ctypes.data, op.nbytes)
+            return [0] + [int(h) for h in hist]
+
+    rng = np.random.default_rng(5)
+    keys = [rng.integers(0, 1 << 31, size=s).astype(np.int64) for s in (70001, 70001, 5)]
+    pay = [rng.integers(0, 1 << 31, size=k.size).astype(np.int32) for k in keys]
+    parts = operators.PartitionGpu(FakeDevice(), list(zip(keys, pay)), 8).Prepare().Run()
+    allk, allp = np.concatenate(keys).astype(np.uint32), np.concatenate(pay).astype(np.uint32)
+    gk, gp = np.concatenate([k for k, _ in parts]), np.concatenate([v for _, v in parts])
+    order_g, order_e = np.lexsort((gp, gk)), np.lexsort((allp, allk))
+    np.testing.assert_array_equal(gk[order_g], allk[order_e])
+    np.testing.assert_array_equal(gp[order_g], allp[order_e])

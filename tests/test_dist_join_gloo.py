@@ -127,7 +127,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, case, outdir, tuple_path):
+def _worker(rank, world, port, case, outdir, tuple_path, order="table", uneven=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -138,13 +138,21 @@ def _worker(rank, world, port, case, outdir, tuple_path):
         # every rank holds an interleaved slice of the rows, cut into two ragged batches
         sl = lambda a: np.ascontiguousarray(a[rank::world])
         cut = lambda a: [a[: a.size // 3], a[a.size // 3:]]
+        if uneven:   # the ranks hold DIFFERENT numbers of batches (1, 3, 0, 2, ...): the collectives issued must not depend on that
+            nb = [1, 3, 0, 2][rank % 4]
+            cut = lambda a: ([a[a.size * i // nb: a.size * (i + 1) // nb] for i in range(nb)] if nb else [])
+            if nb == 0:  # this rank's rows go to its neighbour instead
+                sl = lambda a: np.empty(0, dtype=a.dtype)
+            elif [1, 3, 0, 2][(rank + 1) % 4] == 0 and rank + 1 < world:
+                sl = lambda a: np.ascontiguousarray(np.concatenate([a[rank::world], a[rank + 1::world]]))
         t = lambda a: torch.from_numpy(a.view(np.int32).copy())
         left = [(t(k), t(p)) for k, p in zip(cut(sl(fk)), cut(sl(y)))]
         right = [(t(k), t(p)) for k, p in zip(cut(sl(pk)), cut(sl(x)))]
         ops = {"fused": OracleFusedOps, "tuple": OracleTupleOps, "cols": OracleLocalOps}[tuple_path]()
+        ops.exchange_order = order
         ofk, oy, ox, info = distributed_join(ops, left, right)
         if tuple_path == "fused":
-            assert info["path"] == "fused" and info["groups"] == 2 and info["left_slices"] == 2
+            assert info["path"] == "fused" and info["groups"] == 2 and info["left_slices"] == 2 and info["order"] == order
             assert info["stats"]["presplit"] == (512 // world // 2, 2 * world)
         u = lambda tt: tt.contiguous().numpy().view(np.uint32)
         np.savez(os.path.join(outdir, f"rank{rank}.npz"), fk=u(ofk), y=u(oy), x=u(ox),
@@ -180,6 +188,60 @@ def test_distributed_join_gloo(tmp_path, world, case, tuple_path):
     n_all = g[f"join_{case}_fk"].size + g[f"join_{case}_pk"].size
     assert 0 < total_sent < n_all  # roughly (G-1)/G of the tuples change rank
     assert abs(total_sent / n_all - (world - 1) / world) < 0.1
+
+
+def _check_shards(tmp_path, world, case):
+    g = np.load(os.path.join(GOLDEN_DIR, "arrow_golden.npz"))
+    shards = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    bits = world.bit_length() - 1
+    for r, s in enumerate(shards):
+        if bits:
+            assert (oracle.wang_hash_np(s["fk"]) >> np.uint32(32 - bits) == r).all(), "a rank received keys it does not own"
+    fk, y, x = sort_rows(*(np.concatenate([s[k] for s in shards]) for k in ("fk", "y", "x")))
+    np.testing.assert_array_equal(fk, g[f"join_{case}_out_fk"])
+    np.testing.assert_array_equal(y, g[f"join_{case}_out_y"])
+    np.testing.assert_array_equal(x, g[f"join_{case}_out_x"])
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_distributed_join_group_major_issue_order(tmp_path, world):
+    """exchange_order = "group": both tables are split first, then the exchanges go out as L g0, R g0, L g1, R g1."""
+    mp.spawn(_worker, args=(world, _free_port(), "b", str(tmp_path), "fused", "group"), nprocs=world, join=True)
+    _check_shards(tmp_path, world, "b")
+
+
+@pytest.mark.parametrize("order", ["table", "group"])
+def test_distributed_join_uneven_batch_counts(tmp_path, order):
+    """Ranks holding 1, 3, 0 and 2 batches: the number of left slices (and with it the number of collectives every
+    rank issues) is a knob, not a function of the local batch count -- a rank short of batches ships empty slices."""
+    world = 4
+    mp.spawn(_worker, args=(world, _free_port(), "a", str(tmp_path), "fused", order, True), nprocs=world, join=True)
+    _check_shards(tmp_path, world, "a")
+
+
+def _worker_world1_forced(rank, world, port, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        from dpu_olap_amd.dist_join import distributed_join
+        g = np.load(os.path.join(GOLDEN_DIR, "arrow_golden.npz"))
+        t = lambda a: torch.from_numpy(a.view(np.int32).copy())
+        ops = OracleFusedOps()
+        ops.force_exchange = True
+        ofk, oy, ox, info = distributed_join(ops, [(t(g["join_a_fk"]), t(g["join_a_y"]))], [(t(g["join_a_pk"]), t(g["join_a_x"]))])
+        assert info["path"] == "fused" and info["world"] == 1 and info["left_slices"] == 2 and info["backend"] == "gloo"
+        u = lambda tt: tt.contiguous().numpy().view(np.uint32)
+        np.savez(os.path.join(outdir, "rank0.npz"), fk=u(ofk), y=u(oy), x=u(ox))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_forced_exchange_at_world_size_one(tmp_path):
+    """ops.force_exchange: a process group of ONE rank takes the split -> all-to-all -> pre-split join route (what the
+    GPU test runs over RCCL on a one-GPU box)."""
+    mp.spawn(_worker_world1_forced, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    _check_shards(tmp_path, 1, "a")
 
 
 def test_world_size_one_is_the_plain_join():

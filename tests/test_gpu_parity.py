@@ -202,6 +202,24 @@ def test_partition_vs_oracle(dev, P, space):
     assert [k.size for k, _ in parts] == counts.tolist()
 
 
+@pytest.mark.parametrize("dtype", ["int32", "int64"])
+def test_partition_converted_host_batches(dev, dtype):
+    """Host batches that are not uint32 already are converted (copied) before the C call; the copies must live
+    through it (the pointer tables held addresses of arrays that had been freed)."""
+    o = _ops()
+    rng = np.random.default_rng(11)
+    keys = [rng.integers(0, 1 << 31, size=s).astype(dtype) for s in (50000, 3, 70001)]
+    pay = [rng.integers(0, 1 << 31, size=k.size).astype(dtype) for k in keys]
+    parts = o.PartitionGpu(dev, list(zip(keys, pay)), 64).Prepare().Run()
+    allk, allp = np.concatenate(keys).astype(np.uint32), np.concatenate(pay).astype(np.uint32)
+    bucket = oracle.wang_hash_np(allk) >> np.uint32(26)
+    for p in range(64):
+        ek, ev = sort_rows(allk[bucket == p], allp[bucket == p])
+        gk, gv = sort_rows(*parts[p])
+        np.testing.assert_array_equal(gk, ek)
+        np.testing.assert_array_equal(gv, ev)
+
+
 def test_partition_keys_only_returns_row_ids(dev):
     o = _ops()
     rng = np.random.default_rng(3)
@@ -641,6 +659,40 @@ def test_multirank_fused_split_loopback_on_one_gpu(dev, world):
 
 @pytest.mark.parametrize("case", ["a", "b"])
 @pytest.mark.parametrize("n_seg,chunks,bits", [(4, 3, -1), (16, 2, 9), (1, 5, 3), (64, 1, 8)])
+def test_join_direct_table_checks_the_skipped_hash_bits(dev):
+    """olap_join_set_hash_skip_bits promises that every tuple shares its leading hash bits; the key-less direct-address
+    table is only sound under that promise, so it is checked: inputs that were NOT split by owner are refused with
+    OLAP_ERR_INVALID instead of joining a foreign key to another key's x."""
+    import torch
+    from dpu_olap_amd import capi
+    from dpu_olap_amd.dist_join import GpuLocalOps
+    device = torch.device("cuda", 0)
+    ops = GpuLocalOps(dev, device)
+    rng = np.random.default_rng(21)
+    n = 1 << 16
+    pk = rng.permutation(1 << 20)[:n].astype(np.uint32)
+    x = rng.integers(0, 1 << 32, size=n, dtype=np.uint32)
+    fk = pk[rng.integers(0, n, size=n)]
+    y = rng.integers(0, 1 << 32, size=n, dtype=np.uint32)
+    zip64 = lambda k, p: torch.from_numpy((k.astype(np.uint64) | (p.astype(np.uint64) << np.uint64(32))).view(np.int64)).to(device)
+    owner = lambda k: oracle.wang_hash_np(k) >> np.uint32(30)
+    dev.join_configure(16, 0)          # 2 skipped + 16 radix bits -> 14 bits left: the direct-address table
+    try:
+        with pytest.raises(capi.OlapError) as e:      # all four owners mixed
+            ops.join_tuples(zip64(fk, y), zip64(pk, x), 2)
+        assert e.value.code == capi.ERR_INVALID and "leading hash bits" in str(e.value)
+        lm, rm = owner(fk) == 3, owner(pk) == 3       # split by owner: accepted, rows = the owner's foreign keys
+        ofk, oy, ox, st = ops.join_tuples(zip64(fk[lm], y[lm]), zip64(pk[rm], x[rm]), 2)
+        assert st["missing_keys"] == 0 and ofk.numel() == int(lm.sum()) and st["table_slots"] == 1 << 14
+        got = sort_rows(*(t.cpu().numpy().view(np.uint32) for t in (ofk, oy, ox)))
+        lut = dict(zip(pk.tolist(), x.tolist()))
+        exp = sort_rows(fk[lm], y[lm], np.array([lut[k] for k in fk[lm].tolist()], dtype=np.uint32))
+        for g, ex in zip(got, exp):
+            np.testing.assert_array_equal(g, ex)
+    finally:
+        dev.join_configure(-1, 0)
+
+
 def test_join_presplit_matches_golden(dev, golden, case, n_seg, chunks, bits):
     """olap_join_presplit_u32 on ragged chunks (odd boundaries, an empty sender) against the
     Arrow golden join; rows compared as sorted sets."""
@@ -912,6 +964,19 @@ def test_arrow_c_data_interface_front_end(dev, golden):
     del tbl, sel, out, out64                              # release callbacks run here
     with pytest.raises(ac.capi.OlapError):               # nulls are refused, not silently read
         ac.sum_(dev, pa.chunked_array([pa.array([1, None, 3], type=pa.uint32())]))
+    # null_count == -1 ("not computed", legal in the C Data Interface) with a validity bitmap: the bitmap decides
+    import ctypes as C
+    def sum_with_unknown_null_count(arr):
+        ins, schema, out = ac._Exported([arr]), ac._schema_of(arr.type), C.c_uint64()
+        ins.structs[0].null_count = -1
+        try:
+            return ac._lib().olap_arrow_sum(dev.h, C.byref(schema), ins.table, 1, C.byref(out)), out.value
+        finally:
+            ins.release()
+            ac._release_schema(schema)
+    with_nulls = pa.array([1, None, 3, 4], type=pa.uint32())
+    assert sum_with_unknown_null_count(with_nulls)[0] == ac.capi.ERR_INVALID
+    assert sum_with_unknown_null_count(with_nulls.slice(2)) == (0, 7)     # bitmap present, the slice has no null
 
 
 @pytest.mark.parametrize("space", ["host", "device"])
@@ -969,7 +1034,8 @@ def test_join_ring_scatter_vs_digest(dev, shape, tpt):
     rng = np.random.default_rng(7)
     pk = np.arange(n, dtype=np.uint32) * np.uint32(2654435761) + np.uint32(12345)   # a permutation of distinct keys
     x = dg.uniform_u32(n, dg.SEED, dg.STREAM_X, 0)
-    fk = pk[rng.integers(0, n, size=n)]
+    fk = pk[rng.permutation(n)]
+    fk[: n // 16] = fk[n // 16 : 2 * (n // 16)]     # some repeated foreign keys
     y = dg.uniform_u32(n, dg.SEED, dg.STREAM_Y, 0)
     if shape.startswith("clustered"):
         order = np.argsort(oracle.wang_hash_np(fk), kind="stable")
