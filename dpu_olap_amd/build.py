@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libolap_gpu.so")
-SOURCES = ["ctx.hip", "stage.hip", "scan_ops.hip", "join.hip", "gen.hip", "arrow_c.hip"]
+SOURCES = ["ctx.hip", "stage.hip", "scan_ops.hip", "join.hip", "gen.hip", "arrow_c.hip", "group.hip"]
 ARCH = "gfx950"
 
 
@@ -65,7 +65,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
     if force or jobs or _stale(LIB, objs):
-        run([cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs])
+        run([cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl", "-lpthread"])
     return LIB
 
 

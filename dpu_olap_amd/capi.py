@@ -31,6 +31,8 @@ EXPORTS = [
     "olap_sum", "olap_take", "olap_partition_u32", "olap_partition_tuples_u32", "olap_split_tuples_u32", "olap_join_u32", "olap_join_tuples_u32", "olap_join_presplit_u32", "olap_join_set_right_ready_event", "olap_join_set_unmatched", "olap_join_configure", "olap_join_set_hash_skip_bits", "olap_set_tuning", "olap_get_counter", "olap_phase_kernel",
     "olap_gen_uniform_u32", "olap_gen_uniform_u64", "olap_gen_index_u32", "olap_gen_fk_u32",
     "olap_gen_uniform_u32_at", "olap_checksum", "olap_checksum_rows3_u32",
+    "olap_group_create", "olap_group_destroy", "olap_group_size", "olap_group_ctx", "olap_group_device", "olap_group_last_error",
+    "olap_group_set_transport", "olap_group_last_transport", "olap_group_last_phase_ms", "olap_group_join_u32",
 ]
 
 
@@ -143,6 +145,16 @@ def load_library(path: str | None = None) -> C.CDLL:
         "olap_set_tuning": (i, [vp, C.c_char_p, i]),
         "olap_get_counter": (i, [vp, C.c_char_p, C.POINTER(C.c_uint64)]),
         "olap_phase_kernel": (C.c_char_p, [vp, C.c_char_p]),
+        "olap_group_create": (i, [i, C.POINTER(C.c_int), C.POINTER(vp)]),
+        "olap_group_destroy": (None, [vp]),
+        "olap_group_size": (i, [vp]),
+        "olap_group_ctx": (vp, [vp, i]),
+        "olap_group_device": (i, [vp, i]),
+        "olap_group_last_error": (C.c_char_p, [vp]),
+        "olap_group_set_transport": (i, [vp, i]),
+        "olap_group_last_transport": (i, [vp]),
+        "olap_group_last_phase_ms": (i, [vp, C.POINTER(C.c_double)]),
+        "olap_group_join_u32": (i, [vp, pvp, pvp, pu64, u64, pvp, pvp, pu64, u64, i, vp, vp, vp, u64, pu64, pu64, C.POINTER(JoinStats)]),
         "olap_gen_uniform_u32": (i, [vp, vp, u64, u64, u32, u64]),
         "olap_gen_uniform_u64": (i, [vp, vp, u64, u64, u32, u64]),
         "olap_gen_index_u32": (i, [vp, vp, u64, u32]),
@@ -416,3 +428,70 @@ class Context:
         out = (C.c_uint64 * 2)()
         self._check(self.lib.olap_checksum_rows3_u32(self.h, a, b, c, n, out))
         return out[0], out[1]
+
+
+class _BorrowedContext(Context):
+    """The context of one rank of a Group: owned (and destroyed) by the group."""
+
+    def __init__(self, lib, h, device_id):
+        self.lib, self.h, self.device_id = lib, C.c_void_p(h), device_id
+
+    def close(self):
+        self.h = None
+
+
+TRANSPORT_AUTO, TRANSPORT_COPY, TRANSPORT_RCCL = 0, 1, 2
+
+
+class Group:
+    """olap_group: several devices (or several logical ranks on one device: loopback) behind one handle;
+    the join spans all of them like JoinDpu spans the DpuSet (host/join/join_dpu.cc:82-142,168-400)."""
+
+    def __init__(self, device_ids: Sequence[int]):
+        self.lib = load_library()
+        ids = (C.c_int * len(device_ids))(*device_ids)
+        h = C.c_void_p()
+        rc = self.lib.olap_group_create(len(device_ids), ids, C.byref(h))
+        if rc != OLAP_OK or not h:
+            raise OlapError(rc, f"olap_group_create({list(device_ids)}) failed")
+        self.h = h
+        self.size = self.lib.olap_group_size(self.h)
+        self.ranks = [_BorrowedContext(self.lib, self.lib.olap_group_ctx(self.h, r), device_ids[r]) for r in range(self.size)]
+
+    def close(self):
+        if getattr(self, "h", None):
+            for r in self.ranks:
+                r.close()
+            self.lib.olap_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc != OLAP_OK:
+            raise OlapError(rc, (self.lib.olap_group_last_error(self.h) or b"").decode())
+
+    def set_transport(self, transport: int):
+        self._check(self.lib.olap_group_set_transport(self.h, transport))
+
+    def last_transport(self) -> int:
+        return self.lib.olap_group_last_transport(self.h)
+
+    def last_phase_ms(self) -> dict:
+        ms = (C.c_double * 4)()
+        self._check(self.lib.olap_group_last_phase_ms(self.h, ms))
+        return dict(zip(("split", "exchange", "join", "copy-out"), ms))
+
+    def join_u32(self, lfk, ly, lrows, rpk, rx, rrows, in_mem: int, out_fk: int, out_y: int, out_x: int, out_capacity: int):
+        """-> (rows, rows per rank, stats); the output columns are HOST arrays, rank-major."""
+        n = C.c_uint64()
+        per_rank = (C.c_uint64 * self.size)()
+        st = JoinStats()
+        self._check(self.lib.olap_group_join_u32(self.h, _ptr_table(lfk), _ptr_table(ly), _u64_table(lrows), len(lfk), _ptr_table(rpk),
+                                                 _ptr_table(rx), _u64_table(rrows), len(rpk), in_mem, out_fk, out_y, out_x, out_capacity,
+                                                 C.byref(n), per_rank, C.byref(st)))
+        return n.value, [int(v) for v in per_rank], st.as_dict()

@@ -52,13 +52,26 @@ void CountRows(benchmark::State& state, int64_t rows_per_iteration) {
   state.SetBytesProcessed(rows * (int64_t)sizeof(uint32_t));
 }
 
-std::shared_ptr<olap::Device> DeviceOrSkip(benchmark::State& state) {
-  auto dev = olap::Device::Allocate(0);
+// The device set of a *Gpu benchmark: as many ranks as its "GPUs" argument says.  A host with fewer devices
+// refuses (or runs the ranks on device 0 under OLAP_GROUP_LOOPBACK=1 and says so in the label): a line named
+// GPUs:N always used N ranks.
+std::shared_ptr<olap::Device> DeviceOrSkip(benchmark::State& state, int gpus = 1) {
+  auto dev = olap::Device::Allocate(std::max(1, gpus));
   if (!dev.ok()) {
     state.SkipWithError(dev.status().ToString().c_str());
     return nullptr;
   }
+  if ((*dev)->loopback()) state.SetLabel("loopback: " + std::to_string(gpus) + " logical ranks on device 0");
   return *dev;
+}
+
+// The device-resident variants drive ONE context through the C ABI: a GPUs argument above 1 is refused.
+std::shared_ptr<olap::Device> OneDeviceOrSkip(benchmark::State& state, int64_t gpus) {
+  if (gpus > 1) {
+    state.SkipWithError("the device-resident variants run on one GPU: set NR_GPUS=1 (the multi-GPU join is BM_JoinGpu / bench.py)");
+    return nullptr;
+  }
+  return DeviceOrSkip(state, 1);
 }
 
 // Fixture for the single-column benchmarks: range(0) batches of range(1) rows of "v";
@@ -125,7 +138,7 @@ BENCHMARK_DEFINE_F(FilterFixture, BM_FilterNative)(benchmark::State& state) {
 }
 BENCHMARK_DEFINE_F(FilterFixture, BM_FilterGpu)(benchmark::State& state) {
   if (Skipped(state)) return;
-  auto dev = DeviceOrSkip(state);
+  auto dev = DeviceOrSkip(state, (int)state.range(2));
   if (!dev) return;
   filter::FilterGpu op{*dev, batches_};
   Measure(state, op);
@@ -164,7 +177,7 @@ BENCHMARK_DEFINE_F(SumFixture, BM_SumNative)(benchmark::State& state) {
 }
 BENCHMARK_DEFINE_F(SumFixture, BM_SumGpu)(benchmark::State& state) {
   if (Skipped(state)) return;
-  auto dev = DeviceOrSkip(state);
+  auto dev = DeviceOrSkip(state, (int)state.range(2));
   if (!dev) return;
   aggr::SumGpu op{*dev, batches_};
   Measure(state, op);
@@ -213,7 +226,7 @@ BENCHMARK_DEFINE_F(TakeFixture, BM_TakeNative)(benchmark::State& state) {
 }
 BENCHMARK_DEFINE_F(TakeFixture, BM_TakeGpu)(benchmark::State& state) {
   if (Skipped(state)) return;
-  auto dev = DeviceOrSkip(state);
+  auto dev = DeviceOrSkip(state, (int)state.range(3));
   if (!dev) return;
   take::TakeGpu op{*dev, batches_, indices_};
   Measure(state, op);
@@ -277,7 +290,7 @@ BENCHMARK_DEFINE_F(JoinFixture, BM_JoinNative)(benchmark::State& state) {
   Measure(state, op);
 }
 BENCHMARK_DEFINE_F(JoinFixture, BM_JoinGpu)(benchmark::State& state) {
-  auto dev = DeviceOrSkip(state);
+  auto dev = DeviceOrSkip(state, (int)state.range(3));
   if (!dev) return;
   join::JoinGpu op{*dev, left_.front()->schema(), right_.front()->schema(), left_, right_};
   Measure(state, op);
@@ -315,6 +328,10 @@ class PartitionFixture : public benchmark::Fixture {
 };
 
 BENCHMARK_DEFINE_F(PartitionFixture, BM_PartitionGpu)(benchmark::State& state) {
+  if (state.range(2) > 1) {  // the standalone partition runs on ONE device (the reference's PartitionDpu is a stub, partition_dpu.cc:50-135)
+    state.SkipWithError("BM_PartitionGpu runs on one GPU: set NR_GPUS=1 for this benchmark");
+    return;
+  }
   auto dev = DeviceOrSkip(state);
   if (!dev) return;
   partition::PartitionGpu op{*dev, schema_, batches_, (uint32_t)state.range(3), "pk"};
@@ -391,7 +408,7 @@ class ResidentOp : public GpuOperator {
 constexpr uint64_t kSeed = 42;
 
 static void BM_FilterGpuResident(benchmark::State& state) {
-  auto dev = DeviceOrSkip(state);
+  auto dev = OneDeviceOrSkip(state, state.range(2));
   if (!dev) return;
   const int64_t nb = state.range(0), rows = state.range(1);
   ResidentColumns in(*dev, nb, rows, 1), out(*dev, nb, rows, 1);
@@ -420,7 +437,7 @@ BENCHMARK(BM_FilterGpuResident)
     ->MeasureProcessCPUTime()->UseRealTime()->Unit(benchmark::kMillisecond);
 
 static void BM_SumGpuResident(benchmark::State& state) {
-  auto dev = DeviceOrSkip(state);
+  auto dev = OneDeviceOrSkip(state, state.range(2));
   if (!dev) return;
   const int64_t nb = state.range(0), rows = state.range(1);
   ResidentColumns in(*dev, nb, rows, 1);
@@ -443,7 +460,7 @@ BENCHMARK(BM_SumGpuResident)
     ->MeasureProcessCPUTime()->UseRealTime()->Unit(benchmark::kMillisecond);
 
 static void BM_TakeGpuResident(benchmark::State& state) {
-  auto dev = DeviceOrSkip(state);
+  auto dev = OneDeviceOrSkip(state, state.range(3));
   if (!dev) return;
   const int64_t nb = state.range(0), rows = state.range(1), picks = state.range(2);
   ResidentColumns data(*dev, nb, rows, 1), idx(*dev, nb, picks, 1), out(*dev, nb, picks, 1);
@@ -472,7 +489,7 @@ BENCHMARK(BM_TakeGpuResident)
     ->MeasureProcessCPUTime()->UseRealTime()->Unit(benchmark::kMillisecond);
 
 static void BM_JoinGpuResident(benchmark::State& state) {
-  auto dev = DeviceOrSkip(state);
+  auto dev = OneDeviceOrSkip(state, state.range(3));
   if (!dev) return;
   const int64_t nb = state.range(0), lrows = state.range(1), rrows = state.range(2);
   ResidentColumns left(*dev, nb, lrows, 2), right(*dev, nb, rrows, 2), out(*dev, nb, lrows, 3);

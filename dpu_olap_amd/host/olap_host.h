@@ -81,52 +81,93 @@ class Timers {
 // ------------------------------------------------------------------------ device
 namespace olap {
 
+// The device set an operator runs on: the role of dpu::DpuSet (host/dpuext/dpuext.hpp:687-715).  One rank = one
+// GPU (olap_group over the C ABI); filter / take / sum deal their batches to the ranks, the join spans them all.
 class Device {
  public:
-  static arrow::Result<std::shared_ptr<Device>> Allocate(int device_id = 0) {
-    olap_ctx* ctx = nullptr;
-    const int rc = olap_create(device_id, &ctx);
-    if (rc != OLAP_OK) return arrow::Status::UnknownError("olap_create failed with code ", rc, " (no usable HIP device?)");
-    return std::shared_ptr<Device>(new Device(ctx));
+  // `n_ranks` ranks on HIP devices 0 .. n_ranks - 1.  A host with fewer devices can run them as logical ranks of
+  // device 0 (OLAP_GROUP_LOOPBACK=1: every step of the multi-device path on one GPU); without that it is an error --
+  // a result labelled GPUs:N must have used N.
+  static arrow::Result<std::shared_ptr<Device>> Allocate(int n_ranks = 1) {
+    if (n_ranks < 1 || (n_ranks & (n_ranks - 1))) return arrow::Status::Invalid("the number of GPUs must be a power of two, got ", n_ranks);
+    std::vector<int> ids(n_ranks);
+    for (int r = 0; r < n_ranks; ++r) ids[r] = r;
+    olap_group* group = nullptr;
+    int rc = olap_group_create(n_ranks, ids.data(), &group);
+    bool loopback = false;
+    if (rc != OLAP_OK && n_ranks > 1 && variables::from_env("OLAP_GROUP_LOOPBACK", 0)) {
+      std::fill(ids.begin(), ids.end(), 0);
+      rc = olap_group_create(n_ranks, ids.data(), &group);
+      loopback = true;
+    }
+    if (rc != OLAP_OK)
+      return arrow::Status::UnknownError("olap_group_create(", n_ranks, " devices) failed with code ", rc,
+                                         n_ranks > 1 ? " (fewer HIP devices than NR_GPUS? OLAP_GROUP_LOOPBACK=1 runs the ranks on device 0)"
+                                                     : " (no usable HIP device?)");
+    return std::shared_ptr<Device>(new Device(group, loopback));
   }
-  ~Device() { olap_destroy(ctx_); }
+  ~Device() { olap_group_destroy(group_); }
   Device(const Device&) = delete;
   Device& operator=(const Device&) = delete;
 
-  olap_ctx* ctx() const { return ctx_; }
-  uint32_t nr_ranks() const { return 1; }
+  olap_group* group() const { return group_; }
+  olap_ctx* ctx(uint32_t rank = 0) const { return olap_group_ctx(group_, (int)rank); }
+  uint32_t nr_ranks() const { return (uint32_t)olap_group_size(group_); }
+  bool loopback() const { return loopback_; }
 
-  arrow::Status Check(int rc) const {
-    return rc == OLAP_OK ? arrow::Status::OK() : arrow::Status::UnknownError("olap error ", rc, ": ", olap_last_error(ctx_));
+  arrow::Status Check(int rc, uint32_t rank = 0) const {
+    return rc == OLAP_OK ? arrow::Status::OK() : arrow::Status::UnknownError("olap error ", rc, ": ", olap_last_error(ctx(rank)));
+  }
+  arrow::Status CheckGroup(int rc) const {
+    return rc == OLAP_OK ? arrow::Status::OK() : arrow::Status::UnknownError("olap error ", rc, ": ", olap_group_last_error(group_));
+  }
+
+  // fn(rank) on every rank, one host thread per rank (a context is single-caller; distinct contexts are independent)
+  template <class Fn>
+  arrow::Status OnRanks(Fn&& fn) const {
+    const uint32_t n = nr_ranks();
+    if (n == 1) return fn(0u);
+    std::vector<arrow::Status> st(n);
+    std::vector<std::thread> th;
+    for (uint32_t r = 0; r < n; ++r) th.emplace_back([&, r] { st[r] = fn(r); });
+    for (auto& t : th) t.join();
+    for (auto& s : st) ARROW_RETURN_NOT_OK(s);
+    return arrow::Status::OK();
   }
 
   // Prepare() of every operator: HIP-event timers on, counters cleared.
   arrow::Status BeginTimers() const {
-    ARROW_RETURN_NOT_OK(Check(olap_set_profiling(ctx_, 1)));
-    return Check(olap_reset_timers(ctx_));
+    for (uint32_t r = 0; r < nr_ranks(); ++r) {
+      ARROW_RETURN_NOT_OK(Check(olap_set_profiling(ctx(r), 1), r));
+      ARROW_RETURN_NOT_OK(Check(olap_reset_timers(ctx(r)), r));
+    }
+    return arrow::Status::OK();
   }
 
-  // Library phases -> timers: one entry per phase, plus "gpu-work" = everything but the
-  // copies (the reference's dpu-work next to copy-to-dpu / copy-from-dpu).
+  // Library phases -> timers (per rank, like the reference's per-rank timers): one entry per phase, plus
+  // "gpu-work" = everything but the copies (the reference's dpu-work next to copy-to-dpu / copy-from-dpu).
   arrow::Status FoldTimers(timer::Timers* timers) const {
-    const char* names[32];
-    double ms[32];
-    uint64_t launches[32];
-    int n = 0;
-    ARROW_RETURN_NOT_OK(Check(olap_get_timers(ctx_, names, ms, launches, 32, &n)));
-    double work_ms = 0;
-    for (int i = 0; i < std::min(n, 32); ++i) {
-      const std::string name = names[i];
-      timers->Get(name)->Add(std::chrono::nanoseconds((int64_t)(ms[i] * 1e6)));
-      if (name != "copy-to-gpu" && name != "copy-from-gpu") work_ms += ms[i];
+    for (uint32_t r = 0; r < nr_ranks(); ++r) {
+      const char* names[32];
+      double ms[32];
+      uint64_t launches[32];
+      int n = 0;
+      ARROW_RETURN_NOT_OK(Check(olap_get_timers(ctx(r), names, ms, launches, 32, &n), r));
+      double work_ms = 0;
+      for (int i = 0; i < std::min(n, 32); ++i) {
+        const std::string name = names[i];
+        timers->Get(name)->Add(std::chrono::nanoseconds((int64_t)(ms[i] * 1e6)), r);
+        if (name != "copy-to-gpu" && name != "copy-from-gpu") work_ms += ms[i];
+      }
+      timers->Get("gpu-work")->Add(std::chrono::nanoseconds((int64_t)(work_ms * 1e6)), r);
     }
-    timers->Get("gpu-work")->Add(std::chrono::nanoseconds((int64_t)(work_ms * 1e6)));
     return arrow::Status::OK();
   }
 
  private:
-  explicit Device(olap_ctx* ctx) : ctx_(ctx) {}
-  olap_ctx* ctx_;
+  Device(olap_group* group, bool loopback) : group_(group), loopback_(loopback) {}
+  olap_group* group_;
+  bool loopback_;
 };
 
 // (pointer, rows) tables of one column across batches -- the ABI's view of a

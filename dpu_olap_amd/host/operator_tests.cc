@@ -26,7 +26,9 @@ auto Go(Op&& op) -> decltype(op.Run()) {
   return op.Run();
 }
 
-std::shared_ptr<olap::Device> Gpu() { return olap::Device::Allocate(0).ValueOrDie(); }
+// NR_GPUS ranks (default 1); OLAP_GROUP_LOOPBACK=1 runs them as logical ranks of device 0, so the whole multi-device
+// path -- batches dealt to the ranks, owner split, exchange, per-owner join -- is tested on a one-GPU box.
+std::shared_ptr<olap::Device> Gpu() { return olap::Device::Allocate(variables::max_gpus()).ValueOrDie(); }
 
 std::shared_ptr<arrow::Schema> OneColumn(const char* name, std::shared_ptr<arrow::DataType> type = arrow::uint32()) {
   return arrow::schema({arrow::field(name, std::move(type), /*nullable=*/false)});

@@ -17,9 +17,23 @@ arrow::Result<std::shared_ptr<arrow::ChunkedArray>> FilterGpu::GetResult() {
   ARROW_ASSIGN_OR_RAISE(auto out, olap::AllocateOutputs(in.rows, olap::WidthOf(dtype)));
   std::vector<uint64_t> kept(in.rows.size());
   const uint64_t threshold = 1ull << 30;  // the low bytes serve the 32-bit types too
-  ARROW_RETURN_NOT_OK(system_.Check(olap_filter_lt(system_.ctx(), dtype, in.ptrs.data(), in.rows.data(), in.ptrs.size(),
-                                                   OLAP_MEM_HOST, &threshold, out.ptrs.data(), OLAP_MEM_HOST, kept.data(),
-                                                   nullptr)));
+  // batch b runs on rank b mod G (FilterDpu deals its batches to the DPUs in rounds, filter_dpu.cc:104-169); no communication
+  const uint32_t G = system_.nr_ranks();
+  ARROW_RETURN_NOT_OK(system_.OnRanks([&](uint32_t r) {
+    std::vector<const void*> ptrs;
+    std::vector<uint64_t> rows, k;
+    std::vector<void*> outs;
+    for (size_t b = r; b < in.ptrs.size(); b += G) {
+      ptrs.push_back(in.ptrs[b]);
+      rows.push_back(in.rows[b]);
+      outs.push_back(out.ptrs[b]);
+    }
+    k.resize(ptrs.size());
+    ARROW_RETURN_NOT_OK(system_.Check(olap_filter_lt(system_.ctx(r), dtype, ptrs.data(), rows.data(), ptrs.size(), OLAP_MEM_HOST, &threshold,
+                                                     outs.data(), OLAP_MEM_HOST, k.data(), nullptr), r));
+    for (size_t i = 0; i < k.size(); ++i) kept[r + i * G] = k[i];
+    return arrow::Status::OK();
+  }));
   auto build = timers_->New("build-result");
   build->Start();
   arrow::ArrayVector chunks;
@@ -50,9 +64,22 @@ arrow::Result<std::shared_ptr<arrow::Table>> TakeGpu::Run() {
   ARROW_ASSIGN_OR_RAISE(ColumnTable data, olap::MakeColumnTable(batches_, 0));
   ARROW_ASSIGN_OR_RAISE(ColumnTable idx, olap::MakeColumnTable(indices_batches_, 0));
   ARROW_ASSIGN_OR_RAISE(auto out, olap::AllocateOutputs(idx.rows, olap::WidthOf(dtype)));
-  ARROW_RETURN_NOT_OK(system_.Check(olap_take(system_.ctx(), dtype, data.ptrs.data(), data.rows.data(),
-                                              reinterpret_cast<const uint32_t* const*>(idx.ptrs.data()), idx.rows.data(),
-                                              data.ptrs.size(), OLAP_MEM_HOST, out.ptrs.data(), OLAP_MEM_HOST)));
+  const uint32_t G = system_.nr_ranks();  // batch b on rank b mod G, no communication
+  ARROW_RETURN_NOT_OK(system_.OnRanks([&](uint32_t r) {
+    std::vector<const void*> dp;
+    std::vector<const uint32_t*> ip;
+    std::vector<uint64_t> dr, ir;
+    std::vector<void*> op;
+    for (size_t b = r; b < data.ptrs.size(); b += G) {
+      dp.push_back(data.ptrs[b]);
+      dr.push_back(data.rows[b]);
+      ip.push_back(static_cast<const uint32_t*>(idx.ptrs[b]));
+      ir.push_back(idx.rows[b]);
+      op.push_back(out.ptrs[b]);
+    }
+    return system_.Check(olap_take(system_.ctx(r), dtype, dp.data(), dr.data(), ip.data(), ir.data(), dp.size(), OLAP_MEM_HOST, op.data(),
+                                   OLAP_MEM_HOST), r);
+  }));
   arrow::RecordBatchVector result;
   for (size_t b = 0; b < idx.rows.size(); ++b) {
     auto column = olap::WrapBuffer(type, (int64_t)idx.rows[b], out.buffers[b]);
@@ -73,8 +100,18 @@ arrow::Result<uint64_t> SumGpu::Run() {
   if (!batches_.empty()) {
     ARROW_ASSIGN_OR_RAISE(const int dtype, olap::DtypeOf(*batches_.front()->column(0)->type()));
     ARROW_ASSIGN_OR_RAISE(ColumnTable in, olap::MakeColumnTable(batches_, 0));
-    ARROW_RETURN_NOT_OK(system_.Check(
-        olap_sum(system_.ctx(), dtype, in.ptrs.data(), in.rows.data(), in.ptrs.size(), OLAP_MEM_HOST, &sum)));
+    const uint32_t G = system_.nr_ranks();  // batch b on rank b mod G; the partial sums are added on the host (aggr_dpu.cc:82-84)
+    std::vector<uint64_t> part(G, 0);
+    ARROW_RETURN_NOT_OK(system_.OnRanks([&](uint32_t r) {
+      std::vector<const void*> ptrs;
+      std::vector<uint64_t> rows;
+      for (size_t b = r; b < in.ptrs.size(); b += G) {
+        ptrs.push_back(in.ptrs[b]);
+        rows.push_back(in.rows[b]);
+      }
+      return system_.Check(olap_sum(system_.ctx(r), dtype, ptrs.data(), rows.data(), ptrs.size(), OLAP_MEM_HOST, &part[r]), r);
+    }));
+    for (uint64_t p : part) sum += p;
   }
   ARROW_RETURN_NOT_OK(Finish());
   return sum;
@@ -193,11 +230,14 @@ arrow::Result<std::shared_ptr<arrow::Table>> JoinGpu::Run() {
     if (c != pk) fields.push_back(right_schema_->field(c));
   std::vector<std::shared_ptr<arrow::Array>> columns;
   uint64_t out_rows = 0;
-  ARROW_RETURN_NOT_OK(system_.Check(olap_join_set_unmatched(system_.ctx(), drop_unmatched_ ? OLAP_UNMATCHED_DROP : OLAP_UNMATCHED_ERROR)));
+  for (uint32_t r = 0; r < system_.nr_ranks(); ++r)
+    ARROW_RETURN_NOT_OK(system_.Check(olap_join_set_unmatched(system_.ctx(r), drop_unmatched_ ? OLAP_UNMATCHED_DROP : OLAP_UNMATCHED_ERROR), r));
   struct Restore {
-    olap_ctx* ctx;
-    ~Restore() { (void)olap_join_set_unmatched(ctx, OLAP_UNMATCHED_ERROR); }
-  } restore{system_.ctx()};
+    olap::Device& dev;
+    ~Restore() {
+      for (uint32_t r = 0; r < dev.nr_ranks(); ++r) (void)olap_join_set_unmatched(dev.ctx(r), OLAP_UNMATCHED_ERROR);
+    }
+  } restore{system_};
   ARROW_ASSIGN_OR_RAISE(auto out, olap::AllocateOutputs({n_left, n_left, n_left}, 4));
   auto* o0 = static_cast<uint32_t*>(out.ptrs[0]);
   auto* o1 = static_cast<uint32_t*>(out.ptrs[1]);
@@ -209,9 +249,10 @@ arrow::Result<std::shared_ptr<arrow::Table>> JoinGpu::Run() {
     const int ly = 1 - fk, rx = 1 - pk;
     ARROW_ASSIGN_OR_RAISE(ColumnTable lpay, olap::MakeColumnTable(left_batches_, ly));
     ARROW_ASSIGN_OR_RAISE(ColumnTable rpay, olap::MakeColumnTable(right_batches_, rx));
-    ARROW_RETURN_NOT_OK(system_.Check(olap_join_u32(system_.ctx(), u32pp(lkey), u32pp(lpay), lkey.rows.data(), lkey.ptrs.size(),
-                                                    u32pp(rkey), u32pp(rpay), rkey.rows.data(), rkey.ptrs.size(), OLAP_MEM_HOST,
-                                                    o0, o1, o2, n_left, OLAP_MEM_HOST, &out_rows, &stats_)));
+    // across all ranks of the device set (one rank: the plain olap_join_u32): owner split, exchange, per-owner join
+    ARROW_RETURN_NOT_OK(system_.CheckGroup(olap_group_join_u32(system_.group(), u32pp(lkey), u32pp(lpay), lkey.rows.data(), lkey.ptrs.size(),
+                                                               u32pp(rkey), u32pp(rpay), rkey.rows.data(), rkey.ptrs.size(), OLAP_MEM_HOST,
+                                                               o0, o1, o2, n_left, &out_rows, nullptr, &stats_)));
     columns.resize(3);
     columns[fk] = olap::WrapBuffer(left_schema_->field(fk)->type(), (int64_t)out_rows, out.buffers[0]);
     columns[ly] = olap::WrapBuffer(left_schema_->field(ly)->type(), (int64_t)out_rows, out.buffers[1]);
@@ -220,6 +261,9 @@ arrow::Result<std::shared_ptr<arrow::Table>> JoinGpu::Run() {
     // any other schema: the join returns selection vectors (left row id, right row id of the
     // match) and every non-key column is gathered through them -- the reference's
     // hash_probe + take per column (join_dpu.cc:325-363)
+    if (system_.nr_ranks() > 1)
+      return arrow::Status::NotImplemented("the multi-device join carries one 32-bit payload per side ({fk, y} x {pk, x}); "
+                                           "wider tables run on one device");
     ARROW_RETURN_NOT_OK(system_.Check(olap_join_u32(system_.ctx(), u32pp(lkey), nullptr, lkey.rows.data(), lkey.ptrs.size(),
                                                     u32pp(rkey), nullptr, rkey.rows.data(), rkey.ptrs.size(), OLAP_MEM_HOST, o0,
                                                     o1, o2, n_left, OLAP_MEM_HOST, &out_rows, &stats_)));

@@ -27,7 +27,8 @@
  *  - OLAP_MEM_DEVICE buffers must be 4-byte (32-bit types) / 8-byte (64-bit
  *    types) aligned; 16-byte alignment takes the vector fast path.
  *  - A context is single-caller (one host thread drives it); distinct contexts
- *    are independent.  One context == one GPU.
+ *    are independent.  One context == one GPU; a device GROUP (olap_group_*, below)
+ *    owns one context per device and runs the join across them.
  *  - All calls are synchronous on return unless stated otherwise.
  */
 #ifndef OLAP_GPU_H_
@@ -289,6 +290,43 @@ int olap_get_counter(olap_ctx* ctx, const char* name, uint64_t* out_value);
  * one partition per GPU), all keys here share those bits; the join's own radix
  * passes then start below them.  0 (default) = use the hash from its top bit. */
 int olap_join_set_hash_skip_bits(olap_ctx* ctx, int bits);
+
+/* ------------------------------------------------------------ device group
+ * Several devices behind one handle: replaces dpu::DpuSet::allocate(n, profile) over MANY DPUs
+ * (host/dpuext/dpuext.hpp:687-715) for the operator that needs them all at once, the join
+ * (JoinDpu::Run_internal spans the whole set, host/join/join_dpu.cc:82-142,168-400).
+ * n_ranks: a power of two in [1, 256]; device_ids[r] = HIP device of rank r.  The ids may repeat:
+ * several logical ranks on one device is the loopback mode that runs the whole multi-device path on
+ * a one-GPU box.  Single process; the group is single-caller like a context.  filter / take / sum
+ * shard by batch without communication: run them per rank on olap_group_ctx(g, r). */
+typedef struct olap_group olap_group;
+int olap_group_create(int n_ranks, const int* device_ids, olap_group** out_group);
+void olap_group_destroy(olap_group* g);
+int olap_group_size(const olap_group* g);
+olap_ctx* olap_group_ctx(olap_group* g, int rank);   /* the context of one rank (owned by the group) */
+int olap_group_device(const olap_group* g, int rank);
+const char* olap_group_last_error(const olap_group* g);
+/* How the tuples travel between the ranks: RCCL (ncclSend / ncclRecv in one group call over a communicator made
+ * by ncclCommInitAll -- needs one device per rank; librccl.so is opened on first use) or plain copies
+ * (hipMemcpyPeerAsync over xGMI, same-device copies in loopback).  AUTO = RCCL when every rank has its own
+ * device, else copies. */
+enum { OLAP_GROUP_TRANSPORT_AUTO = 0, OLAP_GROUP_TRANSPORT_COPY = 1, OLAP_GROUP_TRANSPORT_RCCL = 2 };
+int olap_group_set_transport(olap_group* g, int transport);
+int olap_group_last_transport(const olap_group* g);   /* what the last join used (COPY or RCCL; 0: none yet) */
+/* Wall milliseconds of the last olap_group_join_u32: {split, exchange, join, copy-out}. */
+int olap_group_last_phase_ms(const olap_group* g, double out_ms[4]);
+/* olap_join_u32 across the group.  The batches are dealt to the ranks (batch b -> rank b mod G, as the reference
+ * deals batches to DPUs); with in_mem == OLAP_MEM_DEVICE batch b must live on the device of rank b mod G.  Every
+ * rank splits its share by owner = top log2 G bits of wang_hash(key) (olap_split_tuples_u32), the runs are
+ * exchanged -- the shuffle of host/partition/partitioner.cc:280-375 -- and every rank joins the keys it owns
+ * (olap_join_presplit_u32).  Output: HOST columns, rank-major (rank r's rows at [sum of out_rank_rows[< r], ...)),
+ * inside a rank partition-major like olap_join_u32.  out_rank_rows (G entries) may be NULL.  Both payload
+ * columns are required.  The unmatched-row mode and tuning knobs are those of the ranks' contexts. */
+int olap_group_join_u32(olap_group* g, const uint32_t* const* left_fk_ptrs, const uint32_t* const* left_y_ptrs,
+                        const uint64_t* left_rows, uint64_t n_left_batches, const uint32_t* const* right_pk_ptrs,
+                        const uint32_t* const* right_x_ptrs, const uint64_t* right_rows, uint64_t n_right_batches,
+                        int in_mem, uint32_t* out_fk, uint32_t* out_y, uint32_t* out_x, uint64_t out_capacity,
+                        uint64_t* out_rows, uint64_t* out_rank_rows /* may be NULL */, olap_join_stats* stats /* may be NULL */);
 
 /* --------------------------------------------------------------- generator
  * Synthetic columns with the distributions of host/generator/generator.cc:22-71

@@ -9,5 +9,5 @@ C=$ROOT/dpu_olap_amd/csrc
 mkdir -p $ROOT/ab_libs /tmp/ab_obj
 python -m dpu_olap_amd.build > /dev/null
 hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-function -I $ROOT/include -I $C $FLAGS -c $C/join.hip -o /tmp/ab_obj/join_$NAME.o
-hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/ab_libs/$NAME.so $C/build/ctx.o $C/build/stage.o $C/build/scan_ops.o /tmp/ab_obj/join_$NAME.o $C/build/gen.o $C/build/arrow_c.o
+hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/ab_libs/$NAME.so $C/build/ctx.o $C/build/stage.o $C/build/scan_ops.o /tmp/ab_obj/join_$NAME.o $C/build/gen.o $C/build/arrow_c.o $C/build/group.o -ldl -lpthread
 echo $ROOT/ab_libs/$NAME.so

@@ -85,6 +85,37 @@ def test_cpp_gpu_vs_native_suite(host_build):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("gpus", [2, 4])
+def test_cpp_suite_across_a_device_group_in_loopback(host_build, gpus):
+    """The reference's test cases (FilterTest / TakeTest / SumTest / JoinTest ...) with the operators spanning NR_GPUS
+    ranks like the *Dpu operators span the DpuSet: batches dealt to the ranks, and for the join the owner split, the
+    exchange and the per-owner joins of olap_group_join_u32 -- as logical ranks on the one GPU of this box
+    (OLAP_GROUP_LOOPBACK=1; PartitionTest runs on rank 0)."""
+    env = dict(os.environ, NR_GPUS=str(gpus), OLAP_GROUP_LOOPBACK="1")
+    out = subprocess.run([TEST], capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stdout[-4000:] + out.stderr[-2000:]
+    assert "0 failed" in out.stdout
+
+
+@pytest.mark.gpu
+def test_cpp_benchmark_refuses_a_gpu_count_it_cannot_honour(host_build, tmp_path):
+    """A line named GPUs:N ran on N ranks: on this one-GPU box NR_GPUS=2 is an error unless the loopback mode is asked
+    for, and then the label says so."""
+    out_json = tmp_path / "bm.json"
+    args = [BENCH, "--benchmark_filter=BM_(Join|Sum)Gpu/", f"--benchmark_out={out_json}", "--benchmark_out_format=json"]
+    r = subprocess.run(args, capture_output=True, text=True, env=dict(os.environ, SF="2", NR_GPUS="2"), timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    d = json.load(open(out_json))
+    real = [b for b in d["benchmarks"] if "Batches:0" not in b["name"]]
+    assert real and all(b.get("error_occurred") and "olap_group_create(2 devices)" in b["error_message"] for b in real), real
+    r = subprocess.run(args, capture_output=True, text=True, env=dict(os.environ, SF="2", NR_GPUS="2", OLAP_GROUP_LOOPBACK="1"), timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    d = json.load(open(out_json))
+    real = [b for b in d["benchmarks"] if "Batches:0" not in b["name"]]
+    assert real and all(not b.get("error_occurred") and "GPUs:2" in b["name"] and "loopback" in b.get("label", "") for b in real), real
+
+
+@pytest.mark.gpu
 def test_cpp_gpu_benchmarks_run(host_build, tmp_path):
     out_json = tmp_path / "bm.json"
     env = dict(os.environ, SF="2")

@@ -657,8 +657,6 @@ def test_multirank_fused_split_loopback_on_one_gpu(dev, world):
     assert trows == n and (tsum, txor) == expect
 
 
-@pytest.mark.parametrize("case", ["a", "b"])
-@pytest.mark.parametrize("n_seg,chunks,bits", [(4, 3, -1), (16, 2, 9), (1, 5, 3), (64, 1, 8)])
 def test_join_direct_table_checks_the_skipped_hash_bits(dev):
     """olap_join_set_hash_skip_bits promises that every tuple shares its leading hash bits; the key-less direct-address
     table is only sound under that promise, so it is checked: inputs that were NOT split by owner are refused with
@@ -693,6 +691,8 @@ def test_join_direct_table_checks_the_skipped_hash_bits(dev):
         dev.join_configure(-1, 0)
 
 
+@pytest.mark.parametrize("case", ["a", "b"])
+@pytest.mark.parametrize("n_seg,chunks,bits", [(4, 3, -1), (16, 2, 9), (1, 5, 3), (64, 1, 8)])
 def test_join_presplit_matches_golden(dev, golden, case, n_seg, chunks, bits):
     """olap_join_presplit_u32 on ragged chunks (odd boundaries, an empty sender) against the
     Arrow golden join; rows compared as sorted sets."""
@@ -1109,6 +1109,73 @@ def test_join_ring_scatter_skew_falls_back_to_exact(dev):
     assert dev.get_counter("join_attempts") == 2 and dev.get_counter("join_region_overflows") > 0   # the fallback did run
     assert dev.checksum_rows3_u32(out["fk"].ptr, out["y"].ptr, out["x"].ptr, n) == expect
     for c in list(cols.values()) + list(out.values()):
+        dev.release(o.DeviceArray(c.ptr, 0))
+
+
+@pytest.mark.parametrize("ranks", [1, 2, 4, 8])
+@pytest.mark.parametrize("case", ["a", "b"])
+def test_group_join_loopback_vs_golden(golden, ranks, case):
+    """olap_group_*: the join across a device group behind the C ABI, here as `ranks` logical ranks on the ONE device of
+    a gpurun box (loopback: the exchange is same-device copies; on a multi-GPU host the same call moves the runs with
+    RCCL or peer copies).  Host batches in, host columns out (rank-major); rows must equal the Arrow golden join, and
+    every rank must only return keys it owns (top log2 G bits of the Wang hash)."""
+    from dpu_olap_amd import capi
+    fk, y, pk, x = (golden[f"join_{case}_{k}"] for k in ("fk", "y", "pk", "x"))
+    lb, rb = split_batches(fk, golden[f"join_{case}_left_rows"]), split_batches(pk, golden[f"join_{case}_right_rows"])
+    yb, xb = split_batches(y, golden[f"join_{case}_left_rows"]), split_batches(x, golden[f"join_{case}_right_rows"])
+    g = capi.Group([0] * ranks)
+    try:
+        assert g.size == ranks
+        out = [np.empty(fk.size, dtype=np.uint32) for _ in range(3)]
+        ptrs = lambda bs: [b.ctypes.data for b in bs]
+        rows, per_rank, st = g.join_u32(ptrs(lb), ptrs(yb), [b.size for b in lb], ptrs(rb), ptrs(xb), [b.size for b in rb],
+                                        capi.MEM_HOST, *(o.ctypes.data for o in out), fk.size)
+        assert rows == fk.size == sum(per_rank) and st["missing_keys"] == 0 and st["left_rows"] == fk.size
+        if ranks > 1:
+            assert g.last_transport() == capi.TRANSPORT_COPY and set(g.last_phase_ms()) == {"split", "exchange", "join", "copy-out"}
+            owner = oracle.wang_hash_np(out[0]) >> np.uint32(32 - (ranks.bit_length() - 1))
+            assert (np.diff(owner.astype(np.int64)) >= 0).all()                       # rank-major
+            assert np.bincount(owner, minlength=ranks).tolist() == per_rank            # and every rank holds exactly the keys it owns
+        got = sort_rows(*out)
+        for a, k in zip(got, ("fk", "y", "x")):
+            np.testing.assert_array_equal(a, golden[f"join_{case}_out_{k}"])
+        if ranks > 1:   # RCCL needs one device per rank: asked for in loopback it is refused, not silently replaced
+            g.set_transport(capi.TRANSPORT_RCCL)
+            with pytest.raises(capi.OlapError) as e:
+                g.join_u32(ptrs(lb), ptrs(yb), [b.size for b in lb], ptrs(rb), ptrs(xb), [b.size for b in rb],
+                           capi.MEM_HOST, *(o.ctypes.data for o in out), fk.size)
+            assert e.value.code == capi.ERR_INVALID and "one device per rank" in str(e.value)
+    finally:
+        g.close()
+
+
+def test_group_join_device_resident_generator_shape(dev):
+    """Group join on device-resident batches at benchmark shape (SF=16, 4 loopback ranks): digest of the rows against the
+    digest predicted from the inputs."""
+    from dpu_olap_amd import capi, datagen as dg
+    rows, sf, ranks = 2 << 20, 16, 4
+    n = rows * sf
+    o = _ops()
+    cols = {k: dev.empty(n, "uint32") for k in ("fk", "y", "pk", "x", "exp")}
+    dev.gen_fk_u32(cols["fk"].ptr, n, dg.SEED, dg.STREAM_FK, 0, rows, rows)
+    dev.gen_uniform_u32(cols["y"].ptr, n, dg.SEED, dg.STREAM_Y, 0)
+    dev.gen_index_u32(cols["pk"].ptr, n, 0)
+    dev.gen_uniform_u32(cols["x"].ptr, n, dg.SEED, dg.STREAM_X, 0)
+    dev.gen_uniform_u32_at(cols["exp"].ptr, cols["fk"].ptr, n, dg.SEED, dg.STREAM_X)
+    expect = dev.checksum_rows3_u32(cols["fk"].ptr, cols["y"].ptr, cols["exp"].ptr, n)
+    dev.synchronize()
+    g = capi.Group([0] * ranks)
+    try:
+        out = [np.empty(n, dtype=np.uint32) for _ in range(3)]
+        bp = lambda c: [cols[c].ptr + 4 * b * rows for b in range(sf)]
+        got_rows, per_rank, st = g.join_u32(bp("fk"), bp("y"), [rows] * sf, bp("pk"), bp("x"), [rows] * sf, capi.MEM_DEVICE,
+                                            *(a.ctypes.data for a in out), n)
+        assert got_rows == n and st["missing_keys"] == 0 and abs(per_rank[0] / n - 0.25) < 0.01
+    finally:
+        g.close()
+    d = [dev.to_device(a) for a in out]
+    assert dev.checksum_rows3_u32(d[0].ptr, d[1].ptr, d[2].ptr, n) == expect
+    for c in list(cols.values()) + d:
         dev.release(o.DeviceArray(c.ptr, 0))
 
 
