@@ -28,7 +28,7 @@ EXPORTS = [
     "olap_set_stream", "olap_get_stream", "olap_synchronize", "olap_reserve_workspace",
     "olap_workspace_bytes", "olap_malloc", "olap_free", "olap_memcpy_h2d", "olap_memcpy_d2h",
     "olap_memset", "olap_set_profiling", "olap_reset_timers", "olap_get_timers", "olap_filter_lt",
-    "olap_sum", "olap_take", "olap_partition_u32", "olap_partition_tuples_u32", "olap_split_tuples_u32", "olap_join_u32", "olap_join_tuples_u32", "olap_join_presplit_u32", "olap_join_set_right_ready_event", "olap_join_set_unmatched", "olap_join_configure", "olap_join_set_hash_skip_bits", "olap_set_tuning", "olap_get_counter", "olap_phase_kernel",
+    "olap_sum", "olap_take", "olap_partition_u32", "olap_partition_tuples_u32", "olap_split_tuples_u32", "olap_join_u32", "olap_join_u64", "olap_join_tuples_u32", "olap_join_presplit_u32", "olap_join_set_right_ready_event", "olap_join_set_unmatched", "olap_join_configure", "olap_join_set_hash_skip_bits", "olap_set_tuning", "olap_get_counter", "olap_phase_kernel",
     "olap_gen_uniform_u32", "olap_gen_uniform_u64", "olap_gen_index_u32", "olap_gen_fk_u32",
     "olap_gen_uniform_u32_at", "olap_checksum", "olap_checksum_rows3_u32",
     "olap_group_create", "olap_group_destroy", "olap_group_size", "olap_group_ctx", "olap_group_device", "olap_group_last_error",
@@ -136,6 +136,7 @@ def load_library(path: str | None = None) -> C.CDLL:
         "olap_partition_tuples_u32": (i, [vp, pvp, pvp, pu64, u64, i, u32, vp, u64, pu64]),
         "olap_split_tuples_u32": (i, [vp, pvp, pvp, pu64, u64, i, u32, u32, u32, vp, u64, pu64]),
         "olap_join_tuples_u32": (i, [vp, vp, u64, vp, u64, vp, vp, vp, u64, pu64, C.POINTER(JoinStats)]),
+        "olap_join_u64": (i, [vp, pvp, pvp, pu64, u64, pvp, pvp, pu64, u64, i, vp, vp, vp, u64, i, pu64, C.POINTER(JoinStats)]),
         "olap_join_presplit_u32": (i, [vp, vp, u64, pu64, pu64, vp, u64, pu64, pu64, u32, u32, vp, vp, vp, u64, pu64,
                                        C.POINTER(JoinStats)]),
         "olap_join_set_right_ready_event": (i, [vp, vp]),
@@ -400,6 +401,18 @@ class Context:
         self._check(self.lib.olap_join_u32(self.h, _ptr_table(lfk), lyt, _u64_table(lrows), len(lfk),
                                            _ptr_table(rpk), rxt, _u64_table(rrows), len(rpk), in_mem,
                                            out_fk, out_y, out_x, out_capacity, out_mem, C.byref(n), C.byref(st)))
+        return n.value, st.as_dict()
+
+    def join_u64(self, lfk: Sequence[int], ly, lrows, rpk: Sequence[int], rx, rrows, in_mem: int, out_fk: int, out_y: int,
+                 out_x: int, out_capacity: int, out_mem: int):
+        """64-bit keys, 32-bit payloads (ly / rx None: selection vectors).  -> (rows, stats)"""
+        n = C.c_uint64()
+        st = JoinStats()
+        lyt = _ptr_table(ly) if ly is not None else None
+        rxt = _ptr_table(rx) if rx is not None else None
+        self._check(self.lib.olap_join_u64(self.h, _ptr_table(lfk), lyt, _u64_table(lrows), len(lfk), _ptr_table(rpk), rxt,
+                                           _u64_table(rrows), len(rpk), in_mem, out_fk, out_y, out_x, out_capacity, out_mem,
+                                           C.byref(n), C.byref(st)))
         return n.value, st.as_dict()
 
     # -- generator / digests

@@ -18,6 +18,7 @@
 #include "probe_kernels.h"
 #include "radix_kernels.h"
 #include "ring_scatter.h"
+#include "radix64.h"
 
 namespace olap {
 
@@ -1032,3 +1033,5 @@ int olap_split_tuples_u32(olap_ctx* ctx, const uint32_t* const* key_ptrs, const 
 }
 
 }  // extern "C"
+
+#include "join64.h"

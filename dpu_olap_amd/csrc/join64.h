@@ -1,0 +1,257 @@
+// join64.h -- host side of olap_join_u64 (included at the end of join.hip): the radix-partitioned PK-FK join on
+// 64-bit keys with 32-bit payloads, exact layout (histogram + scan + tile-staged scatter per pass), probing LDS
+// table with 64-bit keys.  Device code: radix64.h.  Reference: HT_64BIT_KEYS, dpu/shared/hashtable/hashtable.h:13-18,
+// hashtable.c:23-26; composition as host/join/join_dpu.cc:168-400.
+#pragma once
+
+namespace olap {
+
+static int make_plan64(olap_ctx* ctx, uint32_t total_bits, PassPlan* plan) {
+  if (total_bits < 1) total_bits = 1;
+  const int passes = ((int)total_bits + k64MaxFBits - 1) / k64MaxFBits;
+  if (passes > kMaxPasses) return ctx->fail(OLAP_ERR_INVALID, "%u radix bits need %d passes (max %d)", total_bits, passes, kMaxPasses);
+  plan->passes = passes;
+  plan->total_bits = total_bits;
+  const uint32_t base = total_bits / passes, extra = total_bits % passes;
+  for (int i = 0; i < passes; ++i) plan->bits[i] = base + ((uint32_t)i < extra ? 1u : 0u);
+  return OLAP_OK;
+}
+
+static uint64_t side_scratch_bytes64(const olap_ctx* ctx, uint64_t rows, uint64_t n_batches, const PassPlan& plan) {
+  uint64_t bytes = 0, n_seg = 1;
+  const uint64_t tiles = rows / k64Tile + n_batches + 1;
+  for (int i = 0; i < plan.passes; ++i) {
+    const uint64_t F = 1ull << plan.bits[i];
+    uint64_t blocks = i == 0 ? std::min<uint64_t>((uint64_t)ctx->compute_units * 2, tiles) : n_seg * seg_blocks(ctx, n_seg);
+    if (blocks == 0) blocks = 1;
+    bytes += align_up(blocks * F * 4, 256) + align_up((n_seg * F + 1) * 8, 256);
+    n_seg *= F;
+  }
+  return bytes + 4096;
+}
+
+// all passes of one side; *off_out = [P + 1] partition starts in `fin`
+static int partition_side64(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, const PassPlan& plan, uint4* tmp0, uint4* tmp1,
+                            uint4* fin, const uint64_t** off_out) {
+  const uint64_t rows = cs.view.total_rows;
+  PassSrc src{};
+  src.v = cs.view;
+  src.key_ptrs = cs.dev_ptr_tables[0];
+  src.pay_ptrs = has_payload ? cs.dev_ptr_tables[1] : nullptr;
+  uint64_t n_seg = 1;
+  const uint64_t* seg_in = nullptr;
+  const uint4* in_tuples = nullptr;
+  uint32_t consumed = 0;
+  for (int i = 0; i < plan.passes; ++i) {
+    const uint32_t fbits = plan.bits[i];
+    const uint64_t F = 1ull << fbits;
+    consumed += fbits;
+    const uint32_t shift = 32 - consumed;
+    uint4* out = (i == plan.passes - 1) ? fin : ((i & 1) ? tmp1 : tmp0);
+    const bool cols = i == 0;
+    uint64_t blocks, bseg;
+    if (cols) {
+      const uint64_t tiles = cs.view.total_units;
+      uint64_t nb = std::min<uint64_t>((uint64_t)ctx->compute_units * 2, tiles);
+      if (nb == 0) nb = 1;
+      src.tiles_per_block = std::max<uint64_t>(1, (tiles + nb - 1) / nb);
+      blocks = std::max<uint64_t>(1, (tiles + src.tiles_per_block - 1) / src.tiles_per_block);
+      bseg = blocks;
+    } else {
+      bseg = seg_blocks(ctx, n_seg);
+      blocks = n_seg * bseg;
+      src.tuples = reinterpret_cast<const uint2*>(in_tuples);
+      src.seg_off = seg_in;
+      src.n_seg = (uint32_t)n_seg;
+      src.blocks_per_seg = (uint32_t)bseg;
+    }
+    if (blocks > 0x7FFFFFFFull) return ctx->fail(OLAP_ERR_INVALID, "partition grid too large");
+    uint32_t* hist = (uint32_t*)ws_alloc(ctx, blocks * F * 4);
+    uint64_t* seg_out = (uint64_t*)ws_alloc(ctx, (n_seg * F + 1) * 8);
+    if (!hist || !seg_out) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (64-bit partition pass %d)", i);
+    {
+      PhaseScope ps(ctx, PH_PART_HIST);
+      if (cols) hipLaunchKernelGGL(k64_hist<SRC_COLS>, dim3((unsigned)blocks), dim3(k64Block), 0, ctx->stream, src, shift, fbits, hist);
+      else hipLaunchKernelGGL(k64_hist<SRC_TUPLES>, dim3((unsigned)blocks), dim3(k64Block), 0, ctx->stream, src, shift, fbits, hist);
+      OLAP_HIP(ctx, hipGetLastError());
+    }
+    {
+      PhaseScope ps(ctx, PH_PART_SCAN);
+      hipLaunchKernelGGL(k_part_scan, dim3((unsigned)n_seg), dim3(1024), 0, ctx->stream, hist, seg_in, rows, (uint32_t)n_seg, (uint32_t)bseg,
+                         fbits, seg_out);
+      OLAP_HIP(ctx, hipGetLastError());
+    }
+    {
+      PhaseScope ps(ctx, PH_PART_SCATTER);
+      if (cols) {
+        OLAP_TRY(allow_lds(ctx, reinterpret_cast<const void*>(k64_scatter<SRC_COLS>), k64ScatterLds));
+        ctx->phase_kernel[PH_PART_SCATTER] = "olap::k64_scatter<0>";
+        hipLaunchKernelGGL(k64_scatter<SRC_COLS>, dim3((unsigned)blocks), dim3(k64Block), k64ScatterLds, ctx->stream, src, shift, fbits, hist,
+                           seg_out, out);
+      } else {
+        OLAP_TRY(allow_lds(ctx, reinterpret_cast<const void*>(k64_scatter<SRC_TUPLES>), k64ScatterLds));
+        ctx->phase_kernel[PH_PART_SCATTER] = "olap::k64_scatter<1>";
+        hipLaunchKernelGGL(k64_scatter<SRC_TUPLES>, dim3((unsigned)blocks), dim3(k64Block), k64ScatterLds, ctx->stream, src, shift, fbits,
+                           hist, seg_out, out);
+      }
+      OLAP_HIP(ctx, hipGetLastError());
+    }
+    in_tuples = out;
+    seg_in = seg_out;
+    n_seg *= F;
+  }
+  *off_out = seg_in;
+  return OLAP_OK;
+}
+
+static int join64_once(olap_ctx* ctx, const uint64_t* const* lfk, const uint32_t* const* ly, const uint64_t* lrows, uint64_t lnb,
+                       const uint64_t* const* rpk, const uint32_t* const* rx, const uint64_t* rrows, uint64_t rnb, int in_mem, uint64_t NL,
+                       uint64_t NR, uint32_t total_bits, uint64_t* out_fk, uint32_t* out_y, uint32_t* out_x, int out_mem,
+                       olap_join_stats* st, unsigned long long counters[4], uint64_t* rows_out) {
+  PassPlan plan;
+  OLAP_TRY(make_plan64(ctx, total_bits, &plan));
+  const uint32_t P = 1u << plan.total_bits;
+  const uint32_t eb[2] = {8, 4};
+  const bool l_pay = ly != nullptr, r_pay = rx != nullptr;
+  const void* const* lcols[2] = {(const void* const*)lfk, (const void* const*)ly};
+  const void* const* rcols[2] = {(const void* const*)rpk, (const void* const*)rx};
+  const uint64_t maxN = std::max(NL, NR);
+  const bool drop = ctx->join_drop_unmatched != 0;
+  const uint64_t miss_words = (NL + 31) / 32 + 2, cseg = (NL + kCompactSeg - 1) / kCompactSeg;
+  uint64_t need = column_set_bytes(lrows, lnb, l_pay ? 2 : 1, eb, in_mem) + column_set_bytes(rrows, rnb, r_pay ? 2 : 1, eb, in_mem) +
+                  side_scratch_bytes64(ctx, NL, lnb, plan) + side_scratch_bytes64(ctx, NR, rnb, plan) + align_up((NL + 1) * 16, 256) +
+                  align_up((NR + 1) * 16, 256) + 8192;
+  if (plan.passes >= 2) need += align_up((maxN + 1) * 16, 256);
+  if (plan.passes >= 3) need += align_up((maxN + 1) * 16, 256);
+  if (out_mem == OLAP_MEM_HOST) need += align_up(NL * 8 + 8, 256) + 2 * align_up(NL * 4 + 4, 256);
+  if (drop) need += align_up(miss_words * 4, 256) + align_up(cseg * 4, 256) + align_up((cseg + 1) * 8, 256) + align_up(NL * 8 + 8, 256);
+  OLAP_TRY(pinned_begin(ctx, (lnb + rnb + 2) * 8 * 8 + (cseg + 1) * 12 + 8192));
+  OLAP_TRY(ws_begin(ctx, need));
+  ColumnSet lcs, rcs;
+  OLAP_TRY(build_column_set(ctx, lcols, l_pay ? 2 : 1, eb, lrows, lnb, in_mem, k64Tile, &lcs));
+  OLAP_TRY(build_column_set(ctx, rcols, r_pay ? 2 : 1, eb, rrows, rnb, in_mem, k64Tile, &rcs));
+  uint4* tmp0 = plan.passes >= 2 ? (uint4*)ws_alloc(ctx, (maxN + 1) * 16) : nullptr;
+  uint4* tmp1 = plan.passes >= 3 ? (uint4*)ws_alloc(ctx, (maxN + 1) * 16) : nullptr;
+  uint4* Lt = (uint4*)ws_alloc(ctx, (NL + 1) * 16);
+  uint4* Rt = (uint4*)ws_alloc(ctx, (NR + 1) * 16);
+  unsigned long long* d_cnt = (unsigned long long*)ws_alloc(ctx, 32);
+  uint64_t* d_fk = out_fk;
+  uint32_t *d_y = out_y, *d_x = out_x;
+  if (out_mem == OLAP_MEM_HOST) {
+    d_fk = (uint64_t*)ws_alloc(ctx, NL * 8 + 8);
+    d_y = (uint32_t*)ws_alloc(ctx, NL * 4 + 4);
+    d_x = (uint32_t*)ws_alloc(ctx, NL * 4 + 4);
+  }
+  if ((plan.passes >= 2 && !tmp0) || (plan.passes >= 3 && !tmp1) || !Lt || !Rt || !d_cnt || !d_fk || !d_y || !d_x)
+    return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (64-bit join buffers)");
+  OLAP_HIP(ctx, hipMemsetAsync(d_cnt, 0, 32, ctx->stream));
+  uint32_t* miss_bits = nullptr;
+  if (drop) {
+    miss_bits = (uint32_t*)ws_alloc(ctx, miss_words * 4);
+    if (!miss_bits) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (miss bitmap)");
+    OLAP_HIP(ctx, hipMemsetAsync(miss_bits, 0, miss_words * 4, ctx->stream));
+  }
+  const uint64_t *loff = nullptr, *roff = nullptr;
+  OLAP_TRY(partition_side64(ctx, lcs, l_pay, plan, tmp0, tmp1, Lt, &loff));
+  OLAP_TRY(partition_side64(ctx, rcs, r_pay, plan, tmp0, tmp1, Rt, &roff));
+  {
+    PhaseScope ps(ctx, PH_JOIN_PROBE);
+    ctx->phase_kernel[PH_JOIN_PROBE] = "olap::k64_probe";
+    const uint64_t grid = std::min<uint64_t>((uint64_t)ctx->compute_units * 8, P);
+    hipLaunchKernelGGL(k64_probe, dim3((unsigned)grid), dim3(k64Block), 0, ctx->stream, (const uint4*)Rt, roff, (const uint4*)Lt, loff, P, d_fk,
+                       d_y, d_x, d_cnt, miss_bits);
+    OLAP_HIP(ctx, hipGetLastError());
+  }
+  OLAP_HIP(ctx, hipMemcpyAsync(counters, d_cnt, 32, hipMemcpyDeviceToHost, ctx->stream));
+  OLAP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const bool sound = counters[2] == 0;
+  uint64_t kept_rows = NL;
+  if (drop && sound && counters[0]) {  // inner join: squeeze the marked rows out, order preserved (scratch from the arena)
+    uint32_t* d_kept = (uint32_t*)ws_alloc(ctx, cseg * 4);
+    uint64_t* d_base = (uint64_t*)ws_alloc(ctx, (cseg + 1) * 8);
+    uint64_t* d_tmp = (uint64_t*)ws_alloc(ctx, NL * 8 + 8);
+    uint32_t* h_kept = (uint32_t*)pinned_alloc(ctx, cseg * 4);
+    uint64_t* h_base = (uint64_t*)pinned_alloc(ctx, (cseg + 1) * 8);
+    if (!d_kept || !d_base || !d_tmp || !h_kept || !h_base) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (row compaction)");
+    hipLaunchKernelGGL(k_compact_count, dim3((unsigned)cseg), dim3(256), 0, ctx->stream, (const uint32_t*)miss_bits, NL, d_kept);
+    OLAP_HIP(ctx, hipMemcpyAsync(h_kept, d_kept, cseg * 4, hipMemcpyDeviceToHost, ctx->stream));
+    OLAP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    h_base[0] = 0;
+    for (uint64_t k = 0; k < cseg; ++k) h_base[k + 1] = h_base[k] + h_kept[k];
+    kept_rows = h_base[cseg];
+    if (kept_rows + counters[0] != NL) return ctx->fail(OLAP_ERR_DEVICE, "internal: miss bitmap disagrees with the miss counter");
+    OLAP_HIP(ctx, hipMemcpyAsync(d_base, h_base, (cseg + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k64_compact_rows, dim3((unsigned)cseg), dim3(256), 0, ctx->stream, (const uint64_t*)d_fk, (const uint32_t*)miss_bits,
+                       (const uint64_t*)d_base, NL, d_tmp);
+    OLAP_HIP(ctx, hipMemcpyAsync(d_fk, d_tmp, kept_rows * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    for (uint32_t* col : {d_y, d_x}) {
+      hipLaunchKernelGGL(k_compact_rows, dim3((unsigned)cseg), dim3(256), 0, ctx->stream, (const uint32_t*)col, (const uint32_t*)miss_bits,
+                         (const uint64_t*)d_base, NL, (uint32_t*)d_tmp);
+      OLAP_HIP(ctx, hipMemcpyAsync(col, d_tmp, kept_rows * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    OLAP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  *rows_out = kept_rows;
+  if (out_mem == OLAP_MEM_HOST && sound && (counters[0] == 0 || drop) && kept_rows) {
+    PhaseScope ps(ctx, PH_COPY_FROM);
+    OLAP_TRY(stage_d2h(ctx, {StageItem{d_fk, out_fk, kept_rows * 8}, StageItem{d_y, out_y, kept_rows * 4}, StageItem{d_x, out_x, kept_rows * 4}}));
+    OLAP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  if (st) {
+    st->passes = plan.passes;
+    for (int i = 0; i < 4; ++i) st->radix_bits[i] = i < plan.passes ? plan.bits[i] : 0;
+    st->nr_partitions = P;
+    st->table_slots = k64Slots;
+    st->left_rows = NL;
+    st->right_rows = NR;
+    st->max_build_rows = counters[3];
+    st->duplicate_keys = counters[1];
+    st->missing_keys = counters[0];
+  }
+  return resolve_timers(ctx);
+}
+
+}  // namespace olap
+
+extern "C" int olap_join_u64(olap_ctx* ctx, const uint64_t* const* left_fk_ptrs, const uint32_t* const* left_y_ptrs, const uint64_t* left_rows,
+                             uint64_t n_left_batches, const uint64_t* const* right_pk_ptrs, const uint32_t* const* right_x_ptrs,
+                             const uint64_t* right_rows, uint64_t n_right_batches, int in_mem, uint64_t* out_fk, uint32_t* out_y,
+                             uint32_t* out_x, uint64_t out_capacity, int out_mem, uint64_t* out_rows, olap_join_stats* stats) {
+  using namespace olap;
+  if (!ctx) return OLAP_ERR_INVALID;
+  if (hipSetDevice(ctx->device) != hipSuccess) return ctx->fail(OLAP_ERR_DEVICE, "hipSetDevice failed");
+  if ((in_mem != OLAP_MEM_HOST && in_mem != OLAP_MEM_DEVICE) || (out_mem != OLAP_MEM_HOST && out_mem != OLAP_MEM_DEVICE))
+    return ctx->fail(OLAP_ERR_INVALID, "bad memory space");
+  if (!out_rows) return ctx->fail(OLAP_ERR_INVALID, "out_rows is null");
+  uint64_t NL = 0, NR = 0;
+  OLAP_TRY(check_side(ctx, left_fk_ptrs, left_rows, n_left_batches, &NL));
+  OLAP_TRY(check_side(ctx, right_pk_ptrs, right_rows, n_right_batches, &NR));
+  if (stats) std::memset(stats, 0, sizeof *stats);
+  *out_rows = 0;
+  if (NL == 0) return OLAP_OK;
+  if (NL > out_capacity) return ctx->fail(OLAP_ERR_CAPACITY, "output capacity %llu < %llu left rows", (unsigned long long)out_capacity, (unsigned long long)NL);
+  if (!out_fk || !out_y || !out_x) return ctx->fail(OLAP_ERR_INVALID, "null output column");
+  if (NR == 0) {
+    if (stats) { stats->left_rows = NL; stats->missing_keys = NL; }
+    if (ctx->join_drop_unmatched) return OLAP_OK;
+    return ctx->fail(OLAP_ERR_NO_MATCH, "right table is empty: %llu foreign keys without a match", (unsigned long long)NL);
+  }
+  uint32_t bits = ctx->radix_bits_total >= 0 ? (uint32_t)std::max(1, ctx->radix_bits_total)
+                                             : (uint32_t)std::max(1, ceil_log2_u64((NR + k64TargetBuildRows - 1) / k64TargetBuildRows));
+  unsigned long long counters[4] = {0, 0, 0, 0};
+  uint64_t kept_rows = NL;
+  for (int attempt = 0; attempt < 4; ++attempt) {
+    OLAP_TRY(join64_once(ctx, left_fk_ptrs, left_y_ptrs, left_rows, n_left_batches, right_pk_ptrs, right_x_ptrs, right_rows, n_right_batches,
+                         in_mem, NL, NR, bits, out_fk, out_y, out_x, out_mem, stats, counters, &kept_rows));
+    if (counters[2] == 0) break;
+    bits += 2;  // a build partition overflowed the LDS table: split finer and retry
+    if (bits > 30) break;
+  }
+  if (counters[2])
+    return ctx->fail(OLAP_ERR_OVERFLOW, "%llu partition(s) exceed the LDS hash table (%u rows); largest build partition %llu rows", counters[2],
+                     k64TableCap, counters[3]);
+  if (counters[0] && !ctx->join_drop_unmatched)
+    return ctx->fail(OLAP_ERR_NO_MATCH, "%llu foreign key(s) without a matching primary key", counters[0]);
+  *out_rows = kept_rows;
+  return OLAP_OK;
+}

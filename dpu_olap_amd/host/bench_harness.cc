@@ -538,6 +538,11 @@ int main(int argc, char** argv) {
   if (!arrow::compute::Initialize().ok()) return 2;
   benchmark::AddCustomContext("NR_GPUS", std::to_string(variables::max_gpus()));
   benchmark::AddCustomContext("SF", std::to_string(variables::scale_factor()));
+  // what the *Native operators run on: Arrow's CPU pool (BM_JoinNative uses all of it; the single-column
+  // baselines set their "Threads" argument), next to what the host has
+  if (const char* cap = std::getenv("MAX_THREADS")) (void)arrow::SetCpuThreadPoolCapacity(std::max(1, std::atoi(cap)));
+  benchmark::AddCustomContext("arrow_cpu_threads", std::to_string(arrow::GetCpuThreadPoolCapacity()));
+  benchmark::AddCustomContext("hardware_concurrency", std::to_string(std::thread::hardware_concurrency()));
   benchmark::Initialize(&argc, argv);
   if (benchmark::ReportUnrecognizedArguments(argc, argv)) return 1;
   benchmark::RunSpecifiedBenchmarks();

@@ -279,6 +279,32 @@ TEST(JoinTest, SignedInt32Columns) {
   for (const auto& name : native->schema()->field_names()) EXPECT_TRUE(native->GetColumnByName(name)->Equals(gpu->GetColumnByName(name)));
 }
 
+TEST(JoinTest, Int64Keys) {
+  // 64-bit join keys (the reference's HT_64BIT_KEYS table, hashtable.h:13-18): int64 keys spread over the whole
+  // domain, negative ones included, 32-bit payloads; Gpu result equals Arrow's hash join, key column keeps its type
+  const int n = 200000;
+  arrow::Int64Builder pkb, fkb;
+  arrow::UInt32Builder xb, yb;
+  auto key = [](int64_t i) { return (i - 100000) * 0x100000001LL + (i % 7); };   // distinct, straddles zero, uses the high word
+  for (int i = 0; i < n; ++i) {
+    EXPECT_TRUE(pkb.Append(key(i)).ok());
+    EXPECT_TRUE(xb.Append((uint32_t)(i * 2654435761u)).ok());
+  }
+  for (int i = 0; i < 3 * n; ++i) {
+    EXPECT_TRUE(fkb.Append(key(((int64_t)i * 31) % n)).ok());
+    EXPECT_TRUE(yb.Append((uint32_t)i).ok());
+  }
+  auto right = RecordBatchOf({"pk", "x"}, {pkb.Finish().ValueOrDie(), xb.Finish().ValueOrDie()});
+  auto left = RecordBatchOf({"fk", "y"}, {fkb.Finish().ValueOrDie(), yb.Finish().ValueOrDie()});
+  auto dev = Gpu();
+  auto native = SortedBy(Go(join::JoinNative{left->schema(), right->schema(), {left}, {right}}).ValueOrDie(), {"fk", "y"});
+  auto got = Go(join::JoinGpu{*dev, left->schema(), right->schema(), {left}, {right}}).ValueOrDie();
+  EXPECT_TRUE(got->field(0)->type()->Equals(arrow::int64()));
+  auto gpu = SortedBy(got, {"fk", "y"});
+  EXPECT_EQ(gpu->num_rows(), 3 * n);
+  for (const auto& name : native->schema()->field_names()) EXPECT_TRUE(native->GetColumnByName(name)->Equals(gpu->GetColumnByName(name)));
+}
+
 TEST(JoinTest, MissingForeignKeyIsAnError) {
   auto left = RecordBatchOf({"fk", "y"}, {ArrayOf<U32>({1, 77}), ArrayOf<U32>({5, 6})});
   auto right = RecordBatchOf({"pk", "x"}, {ArrayOf<U32>({1, 2, 3}), ArrayOf<U32>({7, 8, 9})});

@@ -210,16 +210,56 @@ arrow::Result<std::shared_ptr<arrow::Array>> JoinGpu::Gather(const arrow::Record
   return olap::WrapBuffer(field->type(), (int64_t)n, out.buffers[0]);
 }
 
+// 64-bit keys (the reference's HT_64BIT_KEYS table, dpu/shared/hashtable/hashtable.h:13-18): {fk: 64, y: 32} x {pk: 64, x: 32}
+// through olap_join_u64 on rank 0.
+arrow::Result<std::shared_ptr<arrow::Table>> JoinGpu::Run64(int fk, int pk) {
+  auto is32 = [](const arrow::Field& f) { return f.type()->id() == arrow::Type::UINT32 || f.type()->id() == arrow::Type::INT32; };
+  if (left_schema_->num_fields() != 2 || right_schema_->num_fields() != 2 || !is32(*left_schema_->field(1 - fk)) ||
+      !is32(*right_schema_->field(1 - pk)))
+    return arrow::Status::NotImplemented("the 64-bit-key join carries one 32-bit payload column per side");
+  auto outer = timers_->Get("outer");
+  const int ly = 1 - fk, rx = 1 - pk;
+  ARROW_ASSIGN_OR_RAISE(ColumnTable lkey, olap::MakeColumnTable(left_batches_, fk));
+  ARROW_ASSIGN_OR_RAISE(ColumnTable rkey, olap::MakeColumnTable(right_batches_, pk));
+  ARROW_ASSIGN_OR_RAISE(ColumnTable lpay, olap::MakeColumnTable(left_batches_, ly));
+  ARROW_ASSIGN_OR_RAISE(ColumnTable rpay, olap::MakeColumnTable(right_batches_, rx));
+  const uint64_t n_left = lkey.total_rows();
+  ARROW_ASSIGN_OR_RAISE(auto okey, olap::AllocateOutputs({n_left}, 8));
+  ARROW_ASSIGN_OR_RAISE(auto opay, olap::AllocateOutputs({n_left, n_left}, 4));
+  ARROW_RETURN_NOT_OK(system_.Check(olap_join_set_unmatched(system_.ctx(), drop_unmatched_ ? OLAP_UNMATCHED_DROP : OLAP_UNMATCHED_ERROR)));
+  uint64_t out_rows = 0;
+  const int rc = olap_join_u64(system_.ctx(), reinterpret_cast<const uint64_t* const*>(lkey.ptrs.data()),
+                               reinterpret_cast<const uint32_t* const*>(lpay.ptrs.data()), lkey.rows.data(), lkey.ptrs.size(),
+                               reinterpret_cast<const uint64_t* const*>(rkey.ptrs.data()),
+                               reinterpret_cast<const uint32_t* const*>(rpay.ptrs.data()), rkey.rows.data(), rkey.ptrs.size(), OLAP_MEM_HOST,
+                               static_cast<uint64_t*>(okey.ptrs[0]), static_cast<uint32_t*>(opay.ptrs[0]), static_cast<uint32_t*>(opay.ptrs[1]),
+                               n_left, OLAP_MEM_HOST, &out_rows, &stats_);
+  (void)olap_join_set_unmatched(system_.ctx(), OLAP_UNMATCHED_ERROR);
+  ARROW_RETURN_NOT_OK(system_.Check(rc));
+  std::vector<std::shared_ptr<arrow::Array>> columns(3);
+  columns[fk] = olap::WrapBuffer(left_schema_->field(fk)->type(), (int64_t)out_rows, okey.buffers[0]);
+  columns[ly] = olap::WrapBuffer(left_schema_->field(ly)->type(), (int64_t)out_rows, opay.buffers[0]);
+  columns[2] = olap::WrapBuffer(right_schema_->field(rx)->type(), (int64_t)out_rows, opay.buffers[1]);
+  arrow::FieldVector fields = left_schema_->fields();
+  fields.push_back(right_schema_->field(rx));
+  outer->Stop();
+  ARROW_RETURN_NOT_OK(Finish());
+  return arrow::Table::Make(arrow::schema(fields), columns);
+}
+
 arrow::Result<std::shared_ptr<arrow::Table>> JoinGpu::Run() {
   ARROW_RETURN_NOT_OK(Prepared());
   auto outer = timers_->New("outer");
   outer->Start();
   const int fk = left_schema_->GetFieldIndex("fk"), pk = right_schema_->GetFieldIndex("pk");
   if (fk < 0 || pk < 0) return arrow::Status::Invalid("left table needs a column 'fk', right table a column 'pk'");
-  for (const auto& field : {left_schema_->field(fk), right_schema_->field(pk)})
-    if (field->type()->id() != arrow::Type::UINT32 && field->type()->id() != arrow::Type::INT32)
-      return arrow::Status::TypeError("32-bit integer join keys expected, got ", field->ToString());
   auto is32 = [](const arrow::Field& f) { return f.type()->id() == arrow::Type::UINT32 || f.type()->id() == arrow::Type::INT32; };
+  auto is64 = [](const arrow::Field& f) { return f.type()->id() == arrow::Type::UINT64 || f.type()->id() == arrow::Type::INT64; };
+  const bool keys64 = is64(*left_schema_->field(fk)) && is64(*right_schema_->field(pk));
+  if (!keys64)
+    for (const auto& field : {left_schema_->field(fk), right_schema_->field(pk)})
+      if (!is32(*field)) return arrow::Status::TypeError("integer join keys of one width (32 or 64 bits) expected, got ", field->ToString());
+  if (keys64) return Run64(fk, pk);
   ARROW_ASSIGN_OR_RAISE(ColumnTable lkey, olap::MakeColumnTable(left_batches_, fk));
   ARROW_ASSIGN_OR_RAISE(ColumnTable rkey, olap::MakeColumnTable(right_batches_, pk));
   const uint64_t n_left = lkey.total_rows();
@@ -261,9 +301,8 @@ arrow::Result<std::shared_ptr<arrow::Table>> JoinGpu::Run() {
     // any other schema: the join returns selection vectors (left row id, right row id of the
     // match) and every non-key column is gathered through them -- the reference's
     // hash_probe + take per column (join_dpu.cc:325-363)
-    if (system_.nr_ranks() > 1)
-      return arrow::Status::NotImplemented("the multi-device join carries one 32-bit payload per side ({fk, y} x {pk, x}); "
-                                           "wider tables run on one device");
+    // (this form runs on rank 0 alone: the multi-device join carries one 32-bit payload per side, and selection
+    // vectors are row numbers of the WHOLE table, which the per-rank shares do not keep)
     ARROW_RETURN_NOT_OK(system_.Check(olap_join_u32(system_.ctx(), u32pp(lkey), nullptr, lkey.rows.data(), lkey.ptrs.size(),
                                                     u32pp(rkey), nullptr, rkey.rows.data(), rkey.ptrs.size(), OLAP_MEM_HOST, o0,
                                                     o1, o2, n_left, OLAP_MEM_HOST, &out_rows, &stats_)));

@@ -105,6 +105,7 @@ class JoinGpu : public GpuOperator {
   }
 
  private:
+  arrow::Result<std::shared_ptr<arrow::Table>> Run64(int fk, int pk);
   arrow::Result<std::shared_ptr<arrow::Array>> Gather(const arrow::RecordBatchVector& batches, int column,
                                                       const std::shared_ptr<arrow::Field>& field, const uint32_t* ids,
                                                       uint64_t n);

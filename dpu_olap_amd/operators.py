@@ -306,7 +306,40 @@ class JoinGpu(_Op):
         finally:
             self.system_.join_set_unmatched(False)
 
+    @staticmethod
+    def _is64(cols) -> bool:
+        return any(np.dtype(c.dtype).itemsize == 8 for c in cols)
+
+    def _run64(self) -> dict:
+        """64-bit keys (uint64 / int64 bit patterns), 32-bit payloads: olap_join_u64 (the reference's HT_64BIT_KEYS mode)."""
+        k64 = lambda cols: [c if isinstance(c, DeviceArray) else np.ascontiguousarray(c).view(np.uint64) if np.dtype(c.dtype) == np.int64
+                            else np.ascontiguousarray(c, dtype=np.uint64) for c in cols]
+        signed = any(str(np.dtype(c.dtype)) == "int64" for c in list(self.lfk) + list(self.rpk))
+        lfk, rpk = k64(self.lfk), k64(self.rpk)
+        ly, rx = ([], []) if self.select else (self._u32(self.ly), self._u32(self.rx))
+        lp, lrows, lmem, _ = _table(lfk)
+        rp, rrows, rmem, _ = _table(rpk)
+        lyp = None if self.select else _table(ly)[0]
+        rxp = None if self.select else _table(rx)[0]
+        if lmem != rmem:
+            raise ValueError("all join columns must live in the same memory space")
+        n = int(sum(lrows))
+        kdt = "int64" if signed else "uint64"
+        if lmem == capi.MEM_HOST:
+            out = {"fk": np.empty(max(n, 1), dtype=np.uint64), "y": np.empty(max(n, 1), dtype=np.uint32), "x": np.empty(max(n, 1), dtype=np.uint32)}
+            rows, self.stats = self.system_.join_u64(lp, lyp, lrows, rp, rxp, rrows, lmem, out["fk"].ctypes.data, out["y"].ctypes.data,
+                                                     out["x"].ctypes.data, n, capi.MEM_HOST)
+            self._keep = (lfk, rpk, ly, rx)
+            return {"fk": out["fk"][:rows].view(kdt), "y": out["y"][:rows], "x": out["x"][:rows]}
+        out = {"fk": self.system_.empty(n, "uint64"), "y": self.system_.empty(n, "uint32"), "x": self.system_.empty(n, "uint32")}
+        rows, self.stats = self.system_.join_u64(lp, lyp, lrows, rp, rxp, rrows, lmem, out["fk"].ptr, out["y"].ptr, out["x"].ptr, n,
+                                                 capi.MEM_DEVICE)
+        return {"fk": DeviceArray(out["fk"].ptr, rows, kdt), "y": DeviceArray(out["y"].ptr, rows, "uint32"),
+                "x": DeviceArray(out["x"].ptr, rows, "uint32")}
+
     def _run(self) -> dict:
+        if self._is64(self.lfk) or self._is64(self.rpk):
+            return self._run64()
         lfk, rpk = self._u32(self.lfk), self._u32(self.rpk)
         ly, rx = ([], []) if self.select else (self._u32(self.ly), self._u32(self.rx))
         lp, lrows, lmem, _ = _table(lfk)

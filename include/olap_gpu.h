@@ -205,6 +205,19 @@ int olap_join_u32(olap_ctx* ctx, const uint32_t* const* left_fk_ptrs,
                   uint32_t* out_x, uint64_t out_capacity, int out_mem, uint64_t* out_rows,
                   olap_join_stats* stats /* may be NULL */);
 
+/* The join on 64-BIT KEYS (uint64 / int64 bit patterns) with 32-bit payloads: the reference's HT_64BIT_KEYS build
+ * (dpu/shared/hashtable/hashtable.h:13-18: ht_key_t = uint64_t, values stay uint32_t; hash of a 64-bit key
+ * hashtable.c:23-26).  left = {fk: u64, y: u32}, right = {pk: u64, x: u32}, output {fk: u64, y, x}; NULL payload
+ * tables give selection vectors as in olap_join_u32.  Same contract (pk unique, every fk matches unless
+ * OLAP_UNMATCHED_DROP), same statistics; 16-byte tuples through the radix passes (partition = top bits of
+ * wang_hash(hash64(key)), dpu/shared/kernels/partition.c:45-46 applied to the table hash), probing LDS table with
+ * 64-bit keys, slot = hash64(key) & (slots - 1) (hashtable.c:99-101). */
+int olap_join_u64(olap_ctx* ctx, const uint64_t* const* left_fk_ptrs, const uint32_t* const* left_y_ptrs,
+                  const uint64_t* left_rows, uint64_t n_left_batches, const uint64_t* const* right_pk_ptrs,
+                  const uint32_t* const* right_x_ptrs, const uint64_t* right_rows, uint64_t n_right_batches,
+                  int in_mem, uint64_t* out_fk, uint32_t* out_y, uint32_t* out_x, uint64_t out_capacity,
+                  int out_mem, uint64_t* out_rows, olap_join_stats* stats /* may be NULL */);
+
 /* The same join on zipped tuples already resident in HBM (what a rank holds after the
  * all-to-all): left_tuples[i] = fk | y << 32, right_tuples[i] = pk | x << 32, 16-byte
  * aligned device arrays; outputs are device columns. */

@@ -60,6 +60,10 @@ def lib() -> C.CDLL:
             C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), u32p, C.c_uint32,
             C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
         ]
+        L.oracle_ht_hash_u64.restype = C.c_uint32
+        L.oracle_ht_hash_u64.argtypes = [C.c_uint64]
+        L.oracle_join_u64.restype = C.c_uint64
+        L.oracle_join_u64.argtypes = L.oracle_join_u32.argtypes
         L.oracle_max_threads.restype = C.c_int
         _lib = L
     return _lib
@@ -163,6 +167,33 @@ def join(left_fk, left_y, right_pk, right_x, nr_partitions: int = 2, threads: in
         _ptr_array(rp), _ptr_array(rx), rrows.ctypes.data_as(u32p), len(rp),
         nr_partitions, threads, ofk.ctypes.data, oy.ctypes.data, ox.ctypes.data,
     )
+    if n == 0xFFFFFFFFFFFFFFFF:
+        raise KeyError("oracle join: a foreign key has no matching primary key (reference asserts, hash_probe.c:32-33)")
+    n = int(n)
+    return ofk[:n], oy[:n], ox[:n]
+
+
+def ht_hash_u64(key: int) -> int:
+    """hashtable.c:23-26 (HT_64BIT_KEYS)."""
+    return int(lib().oracle_ht_hash_u64(key & 0xFFFFFFFFFFFFFFFF))
+
+
+def join_u64(left_fk, left_y, right_pk, right_x, nr_partitions: int = 2, threads: int = 0):
+    """PK-FK join on 64-bit keys (uint64 / int64 bit patterns) with uint32 payloads; lists of numpy arrays, one per
+    batch.  Returns (fk: uint64, y, x) in the oracle's partition-major order."""
+    lf = [_c(a.view(np.uint64) if a.dtype == np.int64 else a.astype(np.uint64, copy=False)) for a in left_fk]
+    rp = [_c(a.view(np.uint64) if a.dtype == np.int64 else a.astype(np.uint64, copy=False)) for a in right_pk]
+    ly = [_c(a.astype(np.uint32, copy=False)) for a in left_y]
+    rx = [_c(a.astype(np.uint32, copy=False)) for a in right_x]
+    lrows = np.array([a.size for a in lf], dtype=np.uint32)
+    rrows = np.array([a.size for a in rp], dtype=np.uint32)
+    total = int(lrows.sum())
+    ofk = np.empty(max(total, 1), dtype=np.uint64)
+    oy = np.empty(max(total, 1), dtype=np.uint32)
+    ox = np.empty(max(total, 1), dtype=np.uint32)
+    u32p = C.POINTER(C.c_uint32)
+    n = lib().oracle_join_u64(_ptr_array(lf), _ptr_array(ly), lrows.ctypes.data_as(u32p), len(lf), _ptr_array(rp), _ptr_array(rx),
+                              rrows.ctypes.data_as(u32p), len(rp), nr_partitions, threads, ofk.ctypes.data, oy.ctypes.data, ox.ctypes.data)
     if n == 0xFFFFFFFFFFFFFFFF:
         raise KeyError("oracle join: a foreign key has no matching primary key (reference asserts, hash_probe.c:32-33)")
     n = int(n)

@@ -336,3 +336,113 @@ uint64_t oracle_join_u32(const uint32_t* const* left_fk, const uint32_t* const* 
   if (err || misses) return (uint64_t)-1;
   return total_left;
 }
+
+
+/* ------------------------------------------------------------------ 64-bit keys
+ * hashtable.c:23-26 (HT_64BIT_KEYS) */
+uint32_t oracle_ht_hash_u64(uint64_t key) { return (uint32_t)((key >> 33) ^ key ^ (key << 11)); }
+
+typedef struct {
+  uint64_t* key;
+  uint32_t* payload;
+  uint64_t* start; /* [P+1] */
+} side_parts64_t;
+
+/* phase 1 for one side: bucket of every row (partition.c:45-46 on the table hash), stable counting sort over all
+ * batches in batch order (what per-batch kernel_partition + the shuffle of partitioner.cc:280-375 amount to) */
+static int partition_side64(const uint64_t* const* key_cols, const uint32_t* const* pay_cols, const uint32_t* rows, uint32_t nb,
+                            uint32_t P, side_parts64_t* out) {
+  uint64_t total = 0;
+  for (uint32_t b = 0; b < nb; ++b) total += rows[b];
+  int lg = 0;
+  while ((1u << lg) < P) ++lg;
+  out->key = (uint64_t*)malloc((size_t)(total ? total : 1) * sizeof(uint64_t));
+  out->payload = (uint32_t*)malloc((size_t)(total ? total : 1) * sizeof(uint32_t));
+  out->start = (uint64_t*)calloc((size_t)P + 1, sizeof(uint64_t));
+  uint64_t* cur = (uint64_t*)calloc((size_t)P, sizeof(uint64_t));
+  if (!out->key || !out->payload || !out->start || !cur) return -1;
+  for (uint32_t b = 0; b < nb; ++b)
+    for (uint32_t i = 0; i < rows[b]; ++i)
+      out->start[(oracle_wang_hash_u32(oracle_ht_hash_u64(key_cols[b][i])) >> (32 - lg)) + 1]++;
+  for (uint32_t p = 0; p < P; ++p) out->start[p + 1] += out->start[p];
+  memcpy(cur, out->start, (size_t)P * sizeof(uint64_t));
+  for (uint32_t b = 0; b < nb; ++b)
+    for (uint32_t i = 0; i < rows[b]; ++i) {
+      const uint32_t p = oracle_wang_hash_u32(oracle_ht_hash_u64(key_cols[b][i])) >> (32 - lg);
+      out->key[cur[p]] = key_cols[b][i];
+      out->payload[cur[p]] = pay_cols[b][i];
+      cur[p]++;
+    }
+  free(cur);
+  return 0;
+}
+
+uint64_t oracle_join_u64(const uint64_t* const* left_fk, const uint32_t* const* left_y, const uint32_t* left_rows,
+                         uint32_t n_left_batches, const uint64_t* const* right_pk, const uint32_t* const* right_x,
+                         const uint32_t* right_rows, uint32_t n_right_batches, uint32_t P, int threads, uint64_t* out_fk,
+                         uint32_t* out_y, uint32_t* out_x) {
+  if (P < 2 || (P & (P - 1)) != 0) return (uint64_t)-1;
+#ifdef _OPENMP
+  if (threads > 0) omp_set_num_threads(threads);
+#else
+  (void)threads;
+#endif
+  side_parts64_t L, R;
+  memset(&L, 0, sizeof L);
+  memset(&R, 0, sizeof R);
+  uint64_t misses = 0;
+  int err = 0;
+  if (partition_side64(left_fk, left_y, left_rows, n_left_batches, P, &L) != 0 ||
+      partition_side64(right_pk, right_x, right_rows, n_right_batches, P, &R) != 0)
+    err = 1;
+  const uint64_t total_left = err ? 0 : L.start[P];
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : misses)
+  for (uint32_t p = 0; p < (err ? 0 : P); ++p) {
+    const uint64_t r0 = R.start[p], rn = R.start[p + 1] - r0, l0 = L.start[p], ln = L.start[p + 1] - l0;
+    if (ln == 0) continue;
+    const uint32_t cap = next_pow2_u32((uint32_t)(rn * 2 < 64 ? 64 : rn * 2)), mask = cap - 1;
+    uint64_t* tk = (uint64_t*)malloc((size_t)cap * sizeof(uint64_t));
+    uint32_t* tv = (uint32_t*)malloc((size_t)cap * sizeof(uint32_t));
+    uint32_t* used = (uint32_t*)calloc(cap < 32 ? 1 : cap >> 5, sizeof(uint32_t));
+    if (!tk || !tv || !used) {
+#pragma omp atomic write
+      err = 1;
+    } else {
+      for (uint64_t i = 0; i < rn; ++i) { /* ht_put, hashtable.c:89-165: value = right payload (take fused) */
+        const uint64_t key = R.key[r0 + i];
+        uint32_t s = oracle_ht_hash_u64(key) & mask;
+        while (((used[s >> 5] >> (s & 31)) & 1u) && tk[s] != key) s = (s + 1) & mask;
+        used[s >> 5] |= 1u << (s & 31);
+        tk[s] = key;
+        tv[s] = R.payload[r0 + i];
+      }
+      for (uint64_t i = 0; i < ln; ++i) { /* ht_get, hashtable.c:167-192 */
+        const uint64_t key = L.key[l0 + i];
+        uint32_t s = oracle_ht_hash_u64(key) & mask, first = s;
+        int hit = 0;
+        do {
+          if (!((used[s >> 5] >> (s & 31)) & 1u)) break;
+          if (tk[s] == key) {
+            hit = 1;
+            break;
+          }
+          s = (s + 1) & mask;
+        } while (s != first);
+        if (!hit) {
+          ++misses;
+          continue;
+        }
+        out_fk[l0 + i] = key;
+        out_y[l0 + i] = L.payload[l0 + i];
+        out_x[l0 + i] = tv[s];
+      }
+    }
+    free(tk);
+    free(tv);
+    free(used);
+  }
+  free(L.key); free(L.payload); free(L.start);
+  free(R.key); free(R.payload); free(R.start);
+  if (err || misses) return (uint64_t)-1;
+  return total_left;
+}

@@ -118,6 +118,19 @@ uint64_t oracle_join_u32(const uint32_t* const* left_fk, const uint32_t* const* 
                          uint32_t nr_partitions, int threads, uint32_t* out_fk, uint32_t* out_y,
                          uint32_t* out_x);
 
+/* ---- 64-bit keys: the hash table's HT_64BIT_KEYS mode, dpu/shared/hashtable/hashtable.h:13-18 (ht_key_t =
+ *      uint64_t, ht_value_t stays uint32_t) with its hash hashtable.c:23-26:
+ *      (ht_index_t)((key) >> 33 ^ (key) ^ (key) << 11).  Table semantics as above (hashtable.c:89-192). ---- */
+uint32_t oracle_ht_hash_u64(uint64_t key);
+/* Join on 64-bit keys: the composition of oracle_join_u32 with the 64-bit table.  The reference's partition kernel is
+ * written for T = uint32_t (partition.c:20-28,45-46) and defines nothing for 64-bit keys; the restatement applies the
+ * same BUCKET_OF to the table hash: bucket = wang_hash(ht_hash_u64(key)) >> (32 - log2 P).  Partitions keep input
+ * order; rows {fk, y, x} partition-major.  Returns rows, or (uint64_t)-1 on a missing key / bad arguments. */
+uint64_t oracle_join_u64(const uint64_t* const* left_fk, const uint32_t* const* left_y, const uint32_t* left_rows,
+                         uint32_t n_left_batches, const uint64_t* const* right_pk, const uint32_t* const* right_x,
+                         const uint32_t* right_rows, uint32_t n_right_batches, uint32_t nr_partitions, int threads,
+                         uint64_t* out_fk, uint32_t* out_y, uint32_t* out_x);
+
 int oracle_max_threads(void);
 
 #ifdef __cplusplus

@@ -138,6 +138,30 @@ def main():
     jf, jy, jx, jr = arrow_join(fk, y, pk, x)
     out["join_b_out_fk"], out["join_b_out_y"], out["join_b_out_x"], out["join_b_ridx"] = jf, jy, jx, jr
 
+    # ---- joins on 64-bit keys (the reference's HT_64BIT_KEYS mode, hashtable.h:13-18): uint64 keys spread over the
+    # whole domain incl. 0, 2^64 - 1 and keys that differ only above bit 32; int64 keys incl. negatives
+    for name, kdt in (("c", np.uint64), ("d", np.int64)):
+        if kdt is np.uint64:
+            pk = np.unique(np.concatenate([rng.integers(0, 1 << 64, size=7000, dtype=np.uint64, endpoint=False),
+                                           np.array([0, (1 << 64) - 1, 1 << 32, (1 << 32) + 5, 5, 1 << 63], dtype=np.uint64)]))
+        else:
+            pk = np.unique(np.concatenate([rng.integers(-(1 << 63), 1 << 63, size=7000, dtype=np.int64, endpoint=False),
+                                           np.array([0, -1, -(1 << 63), (1 << 63) - 1, 1 << 32, -(1 << 32)], dtype=np.int64)]))
+        rng.shuffle(pk)
+        x = rng.integers(0, 1 << 32, size=pk.size, dtype=np.uint32)
+        fk = pk[rng.integers(0, pk.size, size=10007)]
+        fk[:6] = pk[:6]
+        y = rng.integers(0, 1 << 32, size=fk.size, dtype=np.uint32)
+        left = pa.table({"fk": pa.array(fk), "y": pa.array(y, pa.uint32())})
+        right = pa.table({"pk": pa.array(pk), "x": pa.array(x, pa.uint32())})
+        j = left.join(right, keys="fk", right_keys="pk", join_type="inner").sort_by([("fk", "ascending"), ("y", "ascending"), ("x", "ascending")])
+        out[f"join_{name}_fk"], out[f"join_{name}_y"], out[f"join_{name}_pk"], out[f"join_{name}_x"] = fk, y, pk, x
+        out[f"join_{name}_left_rows"] = np.array([4000, 0, 6007], dtype=np.uint32)
+        out[f"join_{name}_right_rows"] = np.array([pk.size // 2, pk.size - pk.size // 2], dtype=np.uint32)
+        out[f"join_{name}_out_fk"] = j["fk"].to_numpy().astype(kdt)
+        out[f"join_{name}_out_y"] = j["y"].to_numpy().astype(np.uint32)
+        out[f"join_{name}_out_x"] = j["x"].to_numpy().astype(np.uint32)
+
     path = os.path.join(HERE, "arrow_golden.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays; pyarrow", pa.__version__)

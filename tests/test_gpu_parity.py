@@ -1179,6 +1179,88 @@ def test_group_join_device_resident_generator_shape(dev):
         dev.release(o.DeviceArray(c.ptr, 0))
 
 
+# ------------------------------------------------------------ 64-bit join keys
+@pytest.mark.parametrize("case", ["c", "d"])
+@pytest.mark.parametrize("bits,space", [(-1, "host"), (-1, "device"), (7, "host"), (12, "device"), (20, "host")])
+def test_join_u64_vs_arrow_golden(dev, golden, case, bits, space):
+    """olap_join_u64 (HT_64BIT_KEYS, hashtable.h:13-18): uint64 keys incl. 0, 2^64 - 1 (the LDS table's empty marker) and
+    keys that differ only above bit 32 (case c), int64 keys incl. negatives (case d), through 1-, 2- and 3-pass plans
+    of 16-byte tuples; rows must equal Arrow's hash join."""
+    o = _ops()
+    fk, y, pk, x = (golden[f"join_{case}_{k}"] for k in ("fk", "y", "pk", "x"))
+    wrap = (lambda a: a) if space == "host" else dev.to_device
+    lb = [(wrap(k), wrap(v)) for k, v in zip(split_batches(fk, golden[f"join_{case}_left_rows"]), split_batches(y, golden[f"join_{case}_left_rows"]))]
+    rb = [(wrap(k), wrap(v)) for k, v in zip(split_batches(pk, golden[f"join_{case}_right_rows"]), split_batches(x, golden[f"join_{case}_right_rows"]))]
+    dev.join_configure(bits, 0)
+    try:
+        j = o.JoinGpu(dev, lb, rb).Prepare()
+        out = j.Run()
+    finally:
+        dev.join_configure(-1, 0)
+    get = (lambda a: a) if space == "host" else dev.to_host
+    got = sort_rows(get(out["fk"]).view(fk.dtype), get(out["y"]), get(out["x"]))
+    assert j.stats["missing_keys"] == 0 and j.stats["left_rows"] == fk.size and j.stats["table_slots"] == 4096
+    if bits > 0:
+        assert sum(j.stats["radix_bits"]) == bits and j.stats["passes"] == (bits + 8) // 9
+    for g, k in zip(got, ("fk", "y", "x")):
+        np.testing.assert_array_equal(g, golden[f"join_{case}_out_{k}"])
+
+
+def test_join_u64_large_vs_oracle_and_error_modes(dev):
+    """2^22 x 2^22 rows of 64-bit keys in ragged batches against the oracle's join (same hash, same table semantics);
+    then the contract: a missing key is OLAP_ERR_NO_MATCH (or dropped in inner-join mode, order preserved), a
+    duplicate build key overwrites and is counted, NULL payload tables give selection vectors."""
+    o = _ops()
+    from dpu_olap_amd import capi
+    rng = np.random.default_rng(64)
+    n = 1 << 22
+    pk = (rng.permutation(n).astype(np.uint64) << np.uint64(21)) ^ rng.integers(0, 1 << 21, size=n, dtype=np.uint64)   # unique: the top bits are a permutation
+    x = rng.integers(0, 1 << 32, size=n, dtype=np.uint32)
+    fk = pk[rng.integers(0, n, size=n)]
+    y = rng.integers(0, 1 << 32, size=n, dtype=np.uint32)
+    sizes = [n // 3, 5, 0, n - n // 3 - 5]
+    lb = list(zip(split_batches(fk, sizes), split_batches(y, sizes)))
+    rb = list(zip(split_batches(pk, sizes[::-1]), split_batches(x, sizes[::-1])))
+    j = o.JoinGpu(dev, lb, rb).Prepare()
+    out = j.Run()
+    assert j.stats["passes"] == 2 and j.stats["max_build_rows"] <= 3072 and j.stats["missing_keys"] == 0
+    exp = sort_rows(*oracle.join_u64([a for a, _ in lb], [b for _, b in lb], [a for a, _ in rb], [b for _, b in rb], nr_partitions=64))
+    got = sort_rows(out["fk"], out["y"], out["x"])
+    for g, e in zip(got, exp):
+        np.testing.assert_array_equal(g, e)
+    # partition-major output: bucket ids (top bits of wang(hash64)) never decrease
+    h = ((out["fk"] >> np.uint64(33)) ^ out["fk"] ^ (out["fk"] << np.uint64(11))).astype(np.uint32)
+    part = oracle.wang_hash_np(h) >> np.uint32(32 - sum(j.stats["radix_bits"]))
+    assert (np.diff(part.astype(np.int64)) >= 0).all()
+    # missing key
+    small_pk, small_x = pk[:5000].copy(), x[:5000].copy()
+    small_fk = small_pk[rng.integers(0, 5000, size=7000)]
+    small_fk[[10, 4000]] = np.uint64(0xDEADBEEF00000001)
+    small_y = rng.integers(0, 1 << 32, size=7000, dtype=np.uint32)
+    with pytest.raises(capi.OlapError) as e:
+        o.JoinGpu(dev, [(small_fk, small_y)], [(small_pk, small_x)]).Prepare().Run()
+    assert e.value.code == capi.ERR_NO_MATCH
+    jd = o.JoinGpu(dev, [(small_fk, small_y)], [(small_pk, small_x)], drop_unmatched=True).Prepare()
+    od = jd.Run()
+    keep = np.isin(small_fk, small_pk)
+    assert jd.stats["missing_keys"] == 2 and od["fk"].size == 6998
+    lut = dict(zip(small_pk.tolist(), small_x.tolist()))
+    e3 = sort_rows(small_fk[keep], small_y[keep], np.array([lut[k] for k in small_fk[keep].tolist()], dtype=np.uint32))
+    for g, ee in zip(sort_rows(od["fk"], od["y"], od["x"]), e3):
+        np.testing.assert_array_equal(g, ee)
+    # duplicate build key: overwrites (hashtable.c:133), counted
+    dup_pk = np.concatenate([small_pk, small_pk[:3]])
+    dup_x = np.concatenate([small_x, np.array([1, 2, 3], dtype=np.uint32)])
+    jdup = o.JoinGpu(dev, [(small_pk[:100].copy(), small_y[:100].copy())], [(dup_pk, dup_x)]).Prepare()
+    jdup.Run()
+    assert jdup.stats["duplicate_keys"] == 3
+    # selection vectors
+    js = o.JoinGpu(dev, [small_fk[keep].copy()], [small_pk], select=True).Prepare()
+    sel = js.Run()
+    np.testing.assert_array_equal(small_pk[sel["x"]], sel["fk"])
+    np.testing.assert_array_equal(small_fk[keep][sel["y"]], sel["fk"])
+
+
 # ----------------------------------------------------------- randomized shapes
 _FUZZ = int(os.environ.get("OLAP_FUZZ_SEEDS", "0"))   # soak runs: OLAP_FUZZ_SEEDS=500 pytest -m gpu -k random
 

@@ -176,3 +176,20 @@ def test_join_partition_major_layout_and_missing_key(golden):
     np.testing.assert_array_equal(x, 18 - fk)
     with pytest.raises(KeyError):
         oracle.join([np.array([99], dtype=np.uint32)], [np.array([0], dtype=np.uint32)], rp, rx, nr_partitions=2)
+
+
+@pytest.mark.parametrize("case", ["c", "d"])
+@pytest.mark.parametrize("P", [2, 64])
+def test_join_u64_oracle_vs_arrow_golden(golden, case, P):
+    """64-bit keys (the reference's HT_64BIT_KEYS table, hashtable.h:13-18 / hashtable.c:23-26): the oracle's join on
+    uint64 (case c) and int64 (case d) keys equals Arrow's hash join on the same batches; hash KAT of the 64-bit
+    hash function."""
+    assert oracle.ht_hash_u64(0x123456789ABCDEF0) == ((0x123456789ABCDEF0 >> 33) ^ 0x123456789ABCDEF0 ^ (0x123456789ABCDEF0 << 11)) & 0xFFFFFFFF
+    assert oracle.ht_hash_u64(0) == 0 and oracle.ht_hash_u64(1) == 0x801 and oracle.ht_hash_u64(1 << 33) == 1
+    fk, y, pk, x = (golden[f"join_{case}_{k}"] for k in ("fk", "y", "pk", "x"))
+    cut = lambda a, sizes: split_batches(a, sizes)
+    ofk, oy, ox = oracle.join_u64(cut(fk, golden[f"join_{case}_left_rows"]), cut(y, golden[f"join_{case}_left_rows"]),
+                                  cut(pk, golden[f"join_{case}_right_rows"]), cut(x, golden[f"join_{case}_right_rows"]), nr_partitions=P)
+    got = sort_rows(ofk.view(fk.dtype), oy, ox)
+    for g, k in zip(got, ("fk", "y", "x")):
+        np.testing.assert_array_equal(g, golden[f"join_{case}_out_{k}"])
