@@ -105,7 +105,6 @@ static uint64_t side_scratch_bytes(const olap_ctx* ctx, uint64_t rows, uint64_t 
   }
   bytes += align_up(n_seg * 4, 256) + align_up(n_seg * 8, 256);  // capacity-layout tables
   bytes += align_up((1ull << plan.bits[0]) * 4, 256) + align_up((1ull << plan.bits[0]) * 8, 256);  // claim cursors, segment totals
-  bytes += align_up((uint64_t)ctx->compute_units * 2 * (1ull << plan.bits[0]) * 4, 256);            // strided-piece counts
   return bytes + 4096;
 }
 
@@ -151,16 +150,6 @@ static uint32_t claim_cap(const olap_ctx* ctx, uint64_t rows, uint64_t F) {
   while (sd * sd < avg) ++sd;
   const uint64_t cap = align_up(avg + avg / 64 + 8 * sd + (kb + 2) * kClaimChunk, kClaimChunk);
   return cap >= (1ull << 32) ? 0u : (uint32_t)cap;
-}
-
-// Strided-piece layout of the ring scatter's pass 0 (ring_scatter.h): pieces of kSpPiece tuples; a workgroup's area has room for
-// `rounds` pieces per bucket: the expected share of a (workgroup, bucket) pair + 8 sigma + the last, partial piece.
-constexpr uint32_t kSpPiece = 256;
-static uint32_t sp_rounds(uint64_t rows, uint64_t wgs, uint64_t F) {
-  const uint64_t avg = (rows + wgs * F - 1) / (wgs * F);
-  uint64_t sd = 1;
-  while (sd * sd < 2 * avg) ++sd;
-  return (uint32_t)((avg + avg / 64 + 8 * sd + kSpPiece - 1) / kSpPiece + 2);
 }
 
 // Pass 0 of a two-pass plan may run as a claiming scatter (no histogram) when the last pass
@@ -252,36 +241,33 @@ static int launch_claim(olap_ctx* ctx, bool cols, bool g2, unsigned blocks, cons
               : launch_claim_as<SRC_TUPLES, kWBlock, kPTile>(ctx, blocks, src, shift, fbits, out, co);
 }
 
-// ring scatter: pass 0 without histogram (claimed allotments or strided pieces) or capacity-layout last pass; 1024 threads, one
-// workgroup per CU
-template <int SRC, int MODE, int TPT>
+// ring scatter: claiming pass (CLAIM) or capacity-layout pass, 1024 threads, one workgroup per CU
+template <int SRC, bool CLAIM, int TPT>
 static int launch_ring_as(olap_ctx* ctx, unsigned blocks, const PassSrc& src, uint32_t shift, uint32_t fbits, uint2* out, const CapOut& co,
-                          const ClaimOut& cq, const SpOut& sp) {
+                          const ClaimOut& cq) {
   constexpr uint32_t kLds = RingCfg<kRingFmax, kRingLine, kRingBlock, kRingProd>::kBytes;
-  auto kernel = k_part_scatter_ring<SRC, MODE, kRingFmax, kRingLine, kRingBlock, kRingProd, TPT>;
+  auto kernel = k_part_scatter_ring<SRC, CLAIM, kRingFmax, kRingLine, kRingBlock, kRingProd, TPT>;
   OLAP_TRY(allow_lds(ctx, reinterpret_cast<const void*>(kernel), kLds));
   char label[96];
-  std::snprintf(label, sizeof label, "olap::k_part_scatter_ring<%d, %d, %d, %d, %d, %d, %d>", SRC, MODE, kRingFmax, kRingLine, kRingBlock,
-                kRingProd, TPT);
-  ctx->phase_kernel[MODE == RING_CAP ? PH_PART_SCATTER_CAP : PH_PART_SCATTER_CLAIM] = label;
-  hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kRingBlock), kLds, ctx->stream, src, shift, fbits, out, co, cq, sp);
+  std::snprintf(label, sizeof label, "olap::k_part_scatter_ring<%d, %s, %d, %d, %d, %d, %d>", SRC, CLAIM ? "true" : "false", kRingFmax, kRingLine,
+                kRingBlock, kRingProd, TPT);
+  ctx->phase_kernel[CLAIM ? PH_PART_SCATTER_CLAIM : PH_PART_SCATTER_CAP] = label;
+  hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kRingBlock), kLds, ctx->stream, src, shift, fbits, out, co, cq);
   OLAP_HIP(ctx, hipGetLastError());
   return OLAP_OK;
 }
 
-// mode: RING_CAP (input: tuple segments, or the strided pieces of a RING_SP pass when sp_in), RING_CLAIM / RING_SP (pass 0)
-static int launch_ring(olap_ctx* ctx, bool cols, int mode, bool sp_in, unsigned blocks, const PassSrc& src, uint32_t shift, uint32_t fbits,
-                       uint2* out, const CapOut& co, const ClaimOut& cq, const SpOut& sp) {
+static int launch_ring(olap_ctx* ctx, bool cols, bool claim, unsigned blocks, const PassSrc& src, uint32_t shift, uint32_t fbits, uint2* out,
+                       const CapOut& co, const ClaimOut& cq) {
   const bool t4 = ctx->ring_tpt == 4;
-#define OLAP_RING(SRC, MODE) \
-  (t4 ? launch_ring_as<SRC, MODE, 4>(ctx, blocks, src, shift, fbits, out, co, cq, sp) : launch_ring_as<SRC, MODE, 8>(ctx, blocks, src, shift, fbits, out, co, cq, sp))
-  if (mode == RING_CLAIM) return cols ? OLAP_RING(SRC_COLS, RING_CLAIM) : OLAP_RING(SRC_TUPLES, RING_CLAIM);
-  if (mode == RING_SP) return cols ? OLAP_RING(SRC_COLS, RING_SP) : OLAP_RING(SRC_TUPLES, RING_SP);
-  // (reading strided pieces: always 4 tuples per thread -- the piece bookkeeping does not fit 128 VGPRs beside 8; the
-  // capacity pass runs as fast on 2048-tuple tiles, profiles/r2_ab_experiments.md)
-  if (sp_in) return launch_ring_as<SRC_SP, RING_CAP, 4>(ctx, blocks, src, shift, fbits, out, co, cq, sp);
-  return OLAP_RING(SRC_TUPLES, RING_CAP);
-#undef OLAP_RING
+  if (claim) {
+    if (cols) return t4 ? launch_ring_as<SRC_COLS, true, 4>(ctx, blocks, src, shift, fbits, out, co, cq)
+                        : launch_ring_as<SRC_COLS, true, 8>(ctx, blocks, src, shift, fbits, out, co, cq);
+    return t4 ? launch_ring_as<SRC_TUPLES, true, 4>(ctx, blocks, src, shift, fbits, out, co, cq)
+              : launch_ring_as<SRC_TUPLES, true, 8>(ctx, blocks, src, shift, fbits, out, co, cq);
+  }
+  return t4 ? launch_ring_as<SRC_TUPLES, false, 4>(ctx, blocks, src, shift, fbits, out, co, cq)
+            : launch_ring_as<SRC_TUPLES, false, 8>(ctx, blocks, src, shift, fbits, out, co, cq);
 }
 
 // tile-staged scatter without residues (scatter_variant = 1, A/B)
@@ -365,7 +351,6 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
   }
   uint32_t consumed = skip_bits + (pre ? pre->bits : 0u);
   bool claimed_input = false;  // the current input was written by the claiming scatter
-  bool sp_input = false;       // ... in the strided-piece layout
   const bool wc = ctx->scatter_variant == 0;  // write-combining scatter
   for (int i = 0; i < plan.passes; ++i) {
     const uint32_t fbits = plan.bits[i];
@@ -378,8 +363,6 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
     const bool g2 = wc && pass_uses_geometry2(ctx, fbits);  // 512 threads, 4096-tuple tiles, 2 workgroups per CU
     const bool claim_pass = claim && i == 0 && plan.passes == 2 && wc && !pre;  // claiming scatter: no histogram
     const bool ring_claim = claim_pass && ring_ok(ctx, fbits, 1);
-    // strided pieces instead of claimed allotments when the consumer is the ring scatter too (it alone reads that layout)
-    const bool ring_sp = ring_claim && ctx->ring_sp && capm && ring_ok(ctx, plan.bits[plan.passes - 1], 2);
     const bool ring_cap = capm && i == plan.passes - 1 && !(pre_ranges && i == 0) && ring_ok(ctx, fbits, 2);
     if (cols) {
       const uint64_t tiles = cs.view.total_units;
@@ -410,29 +393,6 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
       src.blk_range = ranged ? pre_ranges : nullptr;
     }
     if (blocks > 0x7FFFFFFFull) return ctx->fail(OLAP_ERR_INVALID, "partition grid too large");
-    if (claim_pass && ring_sp) {  // pass 0 in the strided-piece layout: no histogram, no atomics
-      const uint32_t rounds = sp_rounds(rows, blocks, F);
-      const uint64_t area = (uint64_t)rounds * F * kSpPiece;
-      uint32_t* used = (uint32_t*)ws_alloc(ctx, blocks * F * 4);
-      if (!used) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (piece counts)");
-      {
-        PhaseScope ps(ctx, PH_PART_SCATTER_CLAIM);
-        const SpOut sp{used, area, kSpPiece, rounds, d_overflow};
-        OLAP_TRY(launch_ring(ctx, cols, RING_SP, false, (unsigned)blocks, src, shift, fbits, out, CapOut{}, ClaimOut{}, sp));
-      }
-      src.sp_used = used;
-      src.sp_area = area;
-      src.sp_wgs = (uint32_t)blocks;
-      src.sp_f = (uint32_t)F;
-      src.sp_pt = kSpPiece;
-      src.chk_mask = 0;
-      sp_input = true;
-      claimed_input = true;  // (the segments' dense starts are unknown to the consumer: it reports totals)
-      in_tuples = out;
-      seg_in = nullptr;
-      n_seg *= F;
-      continue;
-    }
     if (claim_pass) {
       const uint32_t ccap = claim_cap(ctx, rows, F);
       uint32_t* cursor = (uint32_t*)ws_alloc(ctx, F * 4);
@@ -441,7 +401,7 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
       {
         PhaseScope ps(ctx, PH_PART_SCATTER_CLAIM);
         const ClaimOut co{ccap, cursor, d_overflow};
-        if (ring_claim) OLAP_TRY(launch_ring(ctx, cols, RING_CLAIM, false, (unsigned)blocks, src, shift, fbits, out, CapOut{}, co, SpOut{}));
+        if (ring_claim) OLAP_TRY(launch_ring(ctx, cols, true, (unsigned)blocks, src, shift, fbits, out, CapOut{}, co));
         else OLAP_TRY(launch_claim(ctx, cols, g2, (unsigned)blocks, src, shift, fbits, out, co));
         OLAP_HIP(ctx, hipGetLastError());
       }
@@ -467,8 +427,7 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
         if (!seg_total) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (segment totals)");
       }
       CapOut co{so->cap, so->cnt, so->dense, d_overflow, seg_total};
-      if (sp_input && !ring_cap) return ctx->fail(OLAP_ERR_INVALID, "internal: strided pieces need the ring scatter as their consumer");
-      if (ring_cap) OLAP_TRY(launch_ring(ctx, /*cols=*/false, RING_CAP, sp_input, (unsigned)blocks, src, shift, fbits, out, co, ClaimOut{}, SpOut{}));
+      if (ring_cap) OLAP_TRY(launch_ring(ctx, /*cols=*/false, false, (unsigned)blocks, src, shift, fbits, out, co, ClaimOut{}));
       else OLAP_TRY((launch_scatter<true>(ctx, /*cols=*/false, g2, fbits <= 9 && ctx->line16, (unsigned)blocks, src, shift, fbits, nullptr,
                                           nullptr, out, co)));
       OLAP_HIP(ctx, hipGetLastError());
@@ -573,11 +532,6 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
   uint64_t tmp_tuples = maxN;  // pass-0 output: dense, or the claiming scatter's padded regions
   if (lclaim) tmp_tuples = std::max<uint64_t>(tmp_tuples, ((uint64_t)claim_cap(ctx, NL, 1ull << plan.bits[0])) << plan.bits[0]);
   if (rclaim) tmp_tuples = std::max<uint64_t>(tmp_tuples, ((uint64_t)claim_cap(ctx, NR, 1ull << plan.bits[0])) << plan.bits[0]);
-  if (ctx->ring_sp) {  // strided-piece layout of pass 0: one area per workgroup (an upper bound over both grid shapes)
-    const uint64_t F0 = 1ull << plan.bits[0], wg = (uint64_t)ctx->compute_units;
-    if (lclaim) tmp_tuples = std::max<uint64_t>(tmp_tuples, wg * sp_rounds(NL, wg, F0) * F0 * kSpPiece);
-    if (rclaim) tmp_tuples = std::max<uint64_t>(tmp_tuples, wg * sp_rounds(NR, wg, F0) * F0 * kSpPiece);
-  }
   const bool l_pay = ly != nullptr, r_pay = rx != nullptr;  // null payload: the tuple carries its global row index
   uint64_t need = column_set_bytes(lrows, lnb, l_pay ? 2 : 1, eb, in_mem) + column_set_bytes(rrows, rnb, r_pay ? 2 : 1, eb, in_mem) +
                   side_scratch_bytes(ctx, NL, lnb, plan, in.l_pre) + side_scratch_bytes(ctx, NR, rnb, plan, in.r_pre) +
@@ -814,10 +768,6 @@ int olap_set_tuning(olap_ctx* ctx, const char* key, int value) {
   if (!std::strcmp(key, "ring_scatter")) {
     if (value < 0 || value > 3) return ctx->fail(OLAP_ERR_INVALID, "ring_scatter must be 0 (off), 1 (claiming pass), 2 (capacity pass) or 3 (both)");
     ctx->ring_scatter = value;
-    return OLAP_OK;
-  }
-  if (!std::strcmp(key, "ring_sp")) {
-    ctx->ring_sp = value != 0;
     return OLAP_OK;
   }
   if (!std::strcmp(key, "ring_interleave")) {

@@ -28,7 +28,7 @@ constexpr uint32_t kTableCap = kSlots / 4 * 3;  // max build rows (load <= 0.75,
 constexpr uint32_t kTargetBuildRows = kSlots / 2;
 constexpr uint32_t kEmpty = 0xFFFFFFFFu;
 
-enum { SRC_COLS = 0, SRC_TUPLES = 1, SRC_SP = 2 };  // SRC_SP: the strided-piece layout of the ring scatter (ring_scatter.h only)
+enum { SRC_COLS = 0, SRC_TUPLES = 1 };
 
 // Input of a pass: either the batched key/payload columns (pass 0) or the tuple
 // array of the previous pass cut into segments.
@@ -56,12 +56,6 @@ struct PassSrc {
   uint32_t seg_cap;
   uint32_t chk_shift;
   uint32_t chk_mask;  // 0: every tuple in range is real
-  // SRC_SP: input written by the ring scatter in its strided-piece layout (ring_scatter.h): producer workgroup w wrote the
-  // tuples of bucket b as pieces of sp_pt tuples, piece r at tuple index w * sp_area + (r * sp_f + b) * sp_pt; sp_used[w * sp_f + b]
-  // = tuples it wrote there.  Segment k of this pass = bucket k of the producer.
-  const uint32_t* sp_used;
-  uint64_t sp_area;
-  uint32_t sp_wgs, sp_f, sp_pt;
   // Bucket ORDER of a single-pass split (olap_split_tuples_u32): the bucket id read from the hash is
   // [owner | group | low] (ord_owner_bits, ord_group_bits, ord_low_bits wide); it is emitted as
   // [group | owner | low], so that everything a sub-bucket group sends to all owners is one contiguous run.

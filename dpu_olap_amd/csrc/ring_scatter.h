@@ -25,13 +25,6 @@
 //     reserve is refilled by the PRODUCER thread of that bucket (global atomic on the bucket's cursor,
 //     issued beside its loads and collected with them one tile later, handed over through LDS), so the
 //     atomic's round trip is never waited for and the flushers issue nothing but stores.
-//   * strided pieces (pass 0 of the large-join plan): the claimed allotments above put a workgroup's consecutive line stores
-//     into 512 bucket regions 68 MB apart -- 512 pages, one L1-TLB miss per line (2.9e8 UTCL1 misses per launch against 2.5e3
-//     for the capacity pass, profiles/r2_pmc_ring_claim_layout.txt).  In the SP layout every workgroup owns ONE contiguous
-//     area and writes bucket b's r-th piece (256 tuples) at (r * F + b) * 256 inside it: all buckets advance at about the
-//     same rate, so the lines a workgroup writes at any time lie within a few MiB.  No atomics, no fillers: the
-//     workgroup records how many tuples it wrote per bucket (sp_used), and the next pass (SRC_SP) walks the pieces of
-//     its bucket through all the areas.
 //   * skew: a bucket that receives more than a ring's worth in one tile ("hot") flushes both
 //     lines; the tuples that did not fit are written by their producers straight to a range
 //     the owner reserved for them (one extra barrier, only in tiles where that happens).
@@ -58,23 +51,8 @@ struct RingCfg {
   static constexpr uint32_t kMisc = kList + kNF * kWave * 8;    // hot flag, scan scratch
   static constexpr uint32_t kRsv = kMisc + kNW * 8 + 64;        // CLAIM, per bucket: the allotment claimed ahead (or kRingNone)
   static constexpr uint32_t kWant = kRsv + FMAX * 4;            // CLAIM, per bucket: 1 = claim one more, 2 = claim in flight
-  static constexpr int kSpMaxWgs = 1024;                        // SRC_SP: producer workgroups of the previous pass
-  static constexpr uint32_t kSpPfx = kWant + FMAX * 4;          // SRC_SP: pieces before producer w; its tuple count
-  static constexpr uint32_t kSpCnt = kSpPfx + (kSpMaxWgs + 1) * 4;
-  static constexpr uint32_t kSpTab = ((kSpCnt + kSpMaxWgs * 4 + 15) / 16) * 16;  // SRC_SP: the pieces of the tile being requested {base lo, base hi, valid, -}
-  static constexpr uint32_t kBytes = kSpTab + 96 * 16;  // [0,32) tile 0, [32,64) tile 1 (prologue), [64,96) the tile being requested
+  static constexpr uint32_t kBytes = kWant + FMAX * 4;
   static_assert(FMAX <= kProd, "the producers serve the claims, one bucket per thread");
-};
-
-enum { RING_CAP = 0, RING_CLAIM = 1, RING_SP = 2 };  // output layout: capacity regions | claimed allotments | strided pieces
-
-// Output of the strided-piece layout (MODE RING_SP).
-struct SpOut {
-  uint32_t* used;     // [grid * F]: tuples workgroup w wrote for bucket b
-  uint64_t area;      // tuples per workgroup area = rounds * F * pt
-  uint32_t pt;        // tuples per piece (a multiple of the line, >= 128)
-  uint32_t rounds;    // pieces per bucket an area has room for
-  unsigned long long* overflow;
 };
 
 template <int TPT>
@@ -83,13 +61,12 @@ struct TileRegs {
   uint32_t mask;
 };
 
-// SRC: SRC_COLS (pass 0 from the Arrow columns), SRC_TUPLES, or SRC_SP (the strided pieces a RING_SP pass wrote).
-// MODE: RING_CAP capacity layout (one workgroup per input segment; CapOut), RING_CLAIM claimed allotments + fillers
-// (any number of workgroups per output bucket; ClaimOut), RING_SP strided pieces (SpOut).  Tiles of NPROD * 64 * TPT tuples.
-template <int SRC, int MODE, int FMAX, int LINE, int BLOCK, int NPROD, int TPT>
+// SRC: SRC_COLS (pass 0 from the Arrow columns) or SRC_TUPLES.  CLAIM: claimed allotments + fillers
+// (any number of workgroups per output bucket; ClaimOut) instead of the capacity layout (one
+// workgroup per input segment; CapOut).  Tiles of NPROD * 64 * TPT tuples.
+template <int SRC, bool CLAIM, int FMAX, int LINE, int BLOCK, int NPROD, int TPT>
 __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring(PassSrc s, uint32_t shift, uint32_t fbits, uint2* out, CapOut co,
-                                                               ClaimOut cq, SpOut sp) {
-  constexpr bool CLAIM = MODE == RING_CLAIM, SP = MODE == RING_SP;
+                                                               ClaimOut cq) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using C = RingCfg<FMAX, LINE, BLOCK, NPROD>;
   constexpr int kNF = C::kNF, kProd = C::kProd;
@@ -105,13 +82,7 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring(PassSrc s, uint32_t
   uint32_t* want = (uint32_t*)(smem + C::kWant);
   const uint32_t F = 1u << fbits;
   const uint32_t kRing = (uint32_t)(FMAX * C::kRingMin) >> fbits;  // tuples per bucket ring (a power of two >= 2 * LINE)
-  TileRange r;
-  if constexpr (SRC == SRC_SP) {
-    r.seg = blockIdx.x;
-    r.t0 = r.t1 = r.lo = r.hi = r.a = 0;  // t1: set below, from the producers' counts
-  } else {
-    r = block_tiles<SRC, TILE>(s);
-  }
+  TileRange r = block_tiles<SRC, TILE>(s);
   // Column input, interleaved: at any moment the workgroups read neighbouring tiles -- one contiguous window of each
   // column that moves through it, spread over all HBM channels -- instead of 256 streams that start 64 MiB apart and
   // advance in lockstep (every stream on the same channel at the same time).  tile_at(i) = i-th tile of this workgroup.
@@ -129,53 +100,7 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring(PassSrc s, uint32_t
   const unsigned lane = lane_id();
   const unsigned wave = threadIdx.x / kWave;
   const uint32_t cap = CLAIM ? cq.cap : co.cap;
-  unsigned long long* const overflow = CLAIM ? cq.overflow : SP ? sp.overflow : co.overflow;
-  // Tuple index of logical position `p` of bucket `b`'s output stream of this workgroup.
-  const uint64_t sp_base = SP ? (uint64_t)blockIdx.x * sp.area : 0;
-  auto out_index = [&](uint32_t b, uint32_t p) -> uint64_t {
-    if (SP) return sp_base + ((uint64_t)(p / sp.pt) * F + b) * sp.pt + p % sp.pt;
-    return ((uint64_t)r.seg * F + b) * cap + p;
-  };
-  const uint32_t room = SP ? sp.rounds * sp.pt : cap;  // tuples a bucket's stream may hold
-  // SRC_SP: the pieces of this segment, producer by producer
-  uint32_t* sp_pfx = (uint32_t*)(smem + C::kSpPfx);
-  uint32_t* sp_cnt = (uint32_t*)(smem + C::kSpCnt);
-  uint4* sp_tab = (uint4*)(smem + C::kSpTab);
-  const uint32_t sp_ppt = SRC == SRC_SP ? (uint32_t)TILE / s.sp_pt : 0;  // pieces per tile
-  if constexpr (SRC == SRC_SP) {
-    for (uint32_t w = threadIdx.x; w < s.sp_wgs; w += BLOCK) sp_cnt[w] = s.sp_used[(uint64_t)w * s.sp_f + r.seg];
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      uint32_t run = 0;
-      for (uint32_t w = 0; w < s.sp_wgs; ++w) {
-        sp_pfx[w] = run;
-        run += (sp_cnt[w] + s.sp_pt - 1) / s.sp_pt;
-      }
-      sp_pfx[s.sp_wgs] = run;
-    }
-    __syncthreads();
-    r.t1 = (sp_pfx[s.sp_wgs] + sp_ppt - 1) / sp_ppt;
-  }
-  // piece number q of the segment -> {first tuple index, valid tuples}
-  auto sp_piece = [&](uint32_t q) -> uint4 {
-    if (q >= sp_pfx[s.sp_wgs]) return make_uint4(0u, 0u, 0u, 0u);
-    uint32_t lo = 0, hi = s.sp_wgs;  // last w with sp_pfx[w] <= q
-    while (hi - lo > 1) {
-      const uint32_t mid = (lo + hi) >> 1;
-      if (sp_pfx[mid] <= q) lo = mid; else hi = mid;
-    }
-    const uint32_t rnd = q - sp_pfx[lo];
-    const uint64_t base = (uint64_t)lo * s.sp_area + ((uint64_t)rnd * s.sp_f + r.seg) * s.sp_pt;
-    const uint32_t left = sp_cnt[lo] - rnd * s.sp_pt;
-    return make_uint4((uint32_t)base, (uint32_t)(base >> 32), left < s.sp_pt ? left : s.sp_pt, 0u);
-  };
-  if constexpr (SRC == SRC_SP) {  // the pieces of the first two tiles (sp_ppt <= 32: pieces hold >= 128 tuples)
-    if (threadIdx.x < sp_ppt) {
-      sp_tab[threadIdx.x] = sp_piece(threadIdx.x);
-      sp_tab[32 + threadIdx.x] = sp_piece(sp_ppt + threadIdx.x);
-    }
-    __syncthreads();
-  }
+  unsigned long long* const overflow = CLAIM ? cq.overflow : co.overflow;
   for (uint32_t b = threadIdx.x; b < FMAX + C::kDummy; b += BLOCK) cl[b] = 0;
   if (CLAIM) {
     for (uint32_t b = threadIdx.x; b < FMAX; b += BLOCK) {
@@ -204,40 +129,14 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring(PassSrc s, uint32_t
     A.mask = B.mask = Cc.mask = 0;
 #pragma unroll
     for (int i = 0; i < TPT; ++i) A.bk[i] = B.bk[i] = Cc.bk[i] = dummy;
-    // one tile into registers; SRC_SP: its pieces are listed at sp_tab[tab ...] (LDS, written a barrier ago)
-    auto load_any = [&](uint64_t i, TileRegs<TPT>& t, uint32_t tab) {
-      t.mask = 0;
-      if (!tile_ok(i)) return;
-      if constexpr (SRC == SRC_SP) {
-#pragma unroll
-        for (int j = 0; j < TPT / 2; ++j) {
-          const uint32_t e = (j * kProd + threadIdx.x) * 2;       // tuple offset inside the tile (a wave stays inside one piece)
-          const uint32_t pi = e / s.sp_pt, ei = e % s.sp_pt;
-          const uint4 pc = sp_tab[tab + pi];
-          uint4 v = make_uint4(0, 0, 0, 0);
-          if (ei < pc.z) v = gload4(s.tuples + (((uint64_t)pc.y << 32) | pc.x) + ei);
-          t.key[2 * j] = v.x;
-          t.pay[2 * j] = v.y;
-          t.key[2 * j + 1] = v.z;
-          t.pay[2 * j + 1] = v.w;
-          t.mask |= (ei < pc.z ? 1u : 0u) << (2 * j);
-          t.mask |= (ei + 1 < pc.z ? 1u : 0u) << (2 * j + 1);
-        }
-      } else {
-        t.mask = load_tile<SRC, kProd, true, TILE, OLAP_RING_NT_LOAD != 0>(s, r, tile_at(i), cur, t.key, t.pay);
-      }
-    };
-    load_any(r.t0, A, 0);
-    load_any(r.t0 + 1, B, 32);
+    if (tile_ok(r.t0)) A.mask = load_tile<SRC, kProd, true, TILE, OLAP_RING_NT_LOAD != 0>(s, r, tile_at(r.t0), cur, A.key, A.pay);
+    if (tile_ok(r.t0 + 1)) B.mask = load_tile<SRC, kProd, true, TILE, OLAP_RING_NT_LOAD != 0>(s, r, tile_at(r.t0 + 1), cur, B.key, B.pay);
     hash_tile(A);
     // CLAIM: thread t refills the reserve of bucket t
     const uint32_t tb = threadIdx.x;
     uint32_t claimed = 0;   // the atomic's answer, in flight until the next tile's loads have been awaited
     bool pending = false;
     auto step = [&](uint64_t tile, TileRegs<TPT>& c, TileRegs<TPT>& nx, TileRegs<TPT>& n2) {
-      if constexpr (SRC == SRC_SP) {  // the pieces of tile + 2, for the loads behind barrier 1
-        if (threadIdx.x < sp_ppt) sp_tab[64 + threadIdx.x] = sp_piece((uint32_t)(tile + 2) * sp_ppt + threadIdx.x);
-      }
       // insert tile `tile`: one returning LDS atomic + one LDS store per tuple
       uint32_t v[TPT];
 #pragma unroll
@@ -274,7 +173,8 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring(PassSrc s, uint32_t
           pending = true;
         }
       }
-      load_any(tile + 2, n2, 64);
+      n2.mask = 0;
+      if (tile_ok(tile + 2)) n2.mask = load_tile<SRC, kProd, true, TILE, OLAP_RING_NT_LOAD != 0>(s, r, tile_at(tile + 2), cur, n2.key, n2.pay);
       __syncthreads();  // ---- barrier 2: complete lines are out, the rings have room again
       if (misc[0] == (uint32_t)tile + 1u) {  // some bucket was hot in this tile (uniform)
 #pragma unroll
@@ -284,7 +184,7 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring(PassSrc s, uint32_t
             const uint2 info = hot[b];
             const uint32_t full = info.y & 0xFFFFu, hd = info.y >> 16, sl = v[i] & 0xFFFFu;
             if (sl < full) {  // goes straight to the range the owner reserved (dropped when the region is full)
-              if (info.x != kRingNone) gstore2(out + out_index(b, info.x + (sl - kRing)), make_uint2(c.key[i], c.pay[i]));
+              if (info.x != kRingNone) gstore2(out + ((uint64_t)r.seg * F + b) * cap + info.x + (sl - kRing), make_uint2(c.key[i], c.pay[i]));
             } else {          // tail of the tile: the bucket's new residue
               ring[b * kRing + ((hd + (sl - full)) & (kRing - 1))] = make_uint2(c.key[i], c.pay[i]);
             }
@@ -311,8 +211,7 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring(PassSrc s, uint32_t
     const uint32_t b_own = fw * bpw + lane;
     const bool owner = lane < bpw && b_own < F;
     const uint64_t p_own = (uint64_t)r.seg * F + b_own;
-    // line number of logical position d (a multiple of LINE) of this bucket's stream
-    auto line_of = [&](uint32_t d) { return (uint32_t)(out_index(b_own, d) / LINE); };
+    const uint32_t line0 = (uint32_t)(p_own * cap / LINE);  // first line of the bucket's region (cap is a multiple of LINE)
     uint2* list = (uint2*)(smem + C::kList) + fw * kWave;
     uint32_t pos = 0, rem = 0;                   // next line's tuple offset in the region; CLAIM: tuples left in the allotment
     uint32_t fill_lo = 0, fill_hi = 0;           // CLAIM: unused tail of a hot tile's block
@@ -351,7 +250,7 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring(PassSrc s, uint32_t
       const unsigned long long m = __ballot(has);
       if (!m) return false;
       const uint32_t n = (uint32_t)__popcll(m);
-      if (has) list[__popcll(m & ((1ull << lane) - 1ull))] = make_uint2(line_of(d), b_own * kRing + ring_line);
+      if (has) list[__popcll(m & ((1ull << lane) - 1ull))] = make_uint2(line0 + d / LINE, b_own * kRing + ring_line);
       __builtin_amdgcn_wave_barrier();
       for (uint32_t k = 0; k < n; k += LPI) {
         const uint32_t j = k + lane / LPL;
@@ -382,7 +281,7 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring(PassSrc s, uint32_t
               pos += LINE;
               rem -= LINE;
             }
-          } else if ((uint64_t)pos + LINE > room) {
+          } else if ((uint64_t)pos + LINE > cap) {
             dead = true;
             atomicAdd(overflow, 1ull);
           } else {
@@ -409,7 +308,7 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring(PassSrc s, uint32_t
                 fill_lo = got + nd;
                 fill_hi = got + blk;
               }
-            } else if ((uint64_t)pos + nd > room) {
+            } else if ((uint64_t)pos + nd > cap) {
               dead = true;
               atomicAdd(overflow, 1ull);
             } else {
@@ -457,19 +356,18 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring(PassSrc s, uint32_t
       } else {
         uint32_t count = pos;
         if (!dead) {
-          if ((uint64_t)pos + rr > room) {
+          if ((uint64_t)pos + rr > cap) {
             atomicAdd(overflow, 1ull);
           } else {
-            for (uint32_t j = 0; j < rr; ++j) out[out_index(b_own, pos + j)] = ring[b_own * kRing + ((hd + j) & (kRing - 1))];
+            for (uint32_t j = 0; j < rr; ++j) region[pos + j] = ring[b_own * kRing + ((hd + j) & (kRing - 1))];
             count = pos + rr;
           }
         }
-        if (SP) sp.used[(uint64_t)blockIdx.x * F + b_own] = count;  // what the next pass reads of this bucket here
-        else ((uint32_t*)hot)[b_own] = count;                       // for the closing scan
+        ((uint32_t*)hot)[b_own] = count;  // for the closing scan
       }
     }
   }
-  if (MODE == RING_CAP) {  // partition sizes and dense starts (exclusive scan over this segment's buckets, one per thread)
+  if (!CLAIM) {  // partition sizes and dense starts (exclusive scan over this segment's buckets, one per thread)
     __syncthreads();
     const uint32_t t = threadIdx.x;
     const uint64_t count = t < F ? ((const uint32_t*)hot)[t] : 0u;

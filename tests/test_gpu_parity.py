@@ -1017,9 +1017,9 @@ def test_join_drop_unmatched_is_an_inner_join(dev, space, size):
     assert get(r3["fk"]).size == 0
 
 
-@pytest.mark.parametrize("layout,tpt", [("sp", 8), ("sp", 4), ("claim", 8)])
+@pytest.mark.parametrize("tpt", [8, 4])
 @pytest.mark.parametrize("shape", ["uniform", "clustered_left", "clustered_both", "runs", "ragged"])
-def test_join_ring_scatter_vs_digest(dev, shape, layout, tpt):
+def test_join_ring_scatter_vs_digest(dev, shape, tpt):
     """The ring scatter (csrc/ring_scatter.h: per-bucket LDS rings, 128-byte lines, producer and
     flusher waves) as claiming pass 0 AND as capacity-layout last pass, forced at 2^25 rows with an
     8 + 8 bit plan.  clustered_*: the rows are ordered by their hash, so every tile falls into ONE
@@ -1057,7 +1057,6 @@ def test_join_ring_scatter_vs_digest(dev, shape, layout, tpt):
     dev.set_tuning("claim_mode", 2)
     dev.set_tuning("ring_scatter", 3)
     dev.set_tuning("ring_tpt", tpt)
-    dev.set_tuning("ring_sp", 1 if layout == "sp" else 0)   # pass 0: strided pieces (one area per workgroup) | claimed allotments
     dev.reset_timers()
     try:
         j = o.JoinGpu(dev, [(batch("fk", b), batch("y", b)) for b in range(nb)],
@@ -1068,7 +1067,6 @@ def test_join_ring_scatter_vs_digest(dev, shape, layout, tpt):
         dev.join_configure(-1, 0)
         dev.set_tuning("claim_mode", 1)
         dev.set_tuning("ring_tpt", 8)
-        dev.set_tuning("ring_sp", 1)
     assert out["fk"].rows == n and j.stats["missing_keys"] == 0, j.stats
     assert j.stats["radix_bits"][:2] == [8, 8], j.stats
     assert dev.checksum_rows3_u32(out["fk"].ptr, out["y"].ptr, out["x"].ptr, n) == expect
@@ -1303,7 +1301,7 @@ def test_join_random_shapes_and_plans_vs_oracle(dev, seed):
         bits = -1                               # keep build partitions inside the probing table
     knobs = {"scatter_variant": int(rng.integers(2)), "capacity_mode": int(rng.integers(2)), "claim_mode": int(rng.choice([0, 2])),
              "direct_table": int(rng.integers(2)), "wc_geometry": int(rng.choice([1, 2])), "line16": int(rng.integers(2)),
-             "ring_scatter": int(rng.integers(4)), "ring_tpt": int(rng.choice([4, 8])), "ring_sp": int(rng.integers(2))}
+             "ring_scatter": int(rng.integers(4)), "ring_tpt": int(rng.choice([4, 8]))}
     per_pass = int(rng.choice([0, 0, 3, 5, 8, 10]))
     if per_pass and max(bits, 8) > 4 * per_pass:
         per_pass = 0                            # more than 4 passes is a configuration error
@@ -1316,7 +1314,7 @@ def test_join_random_shapes_and_plans_vs_oracle(dev, seed):
     finally:
         dev.join_configure(-1, 0)
         for k, v in {"scatter_variant": 0, "capacity_mode": 1, "claim_mode": 1, "direct_table": 1, "wc_geometry": 2, "line16": 0,
-                     "ring_scatter": 3, "ring_tpt": 8, "ring_sp": 1}.items():
+                     "ring_scatter": 3, "ring_tpt": 8}.items():
             dev.set_tuning(k, v)
     get = (lambda a: a) if space == "host" else dev.to_host
     got = sort_rows(get(r["fk"]), get(r["y"]), get(r["x"]))
