@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--only", default="")
     ap.add_argument("--cpu", action="store_true", help="also time Arrow compute (CPU) on a bounded sample")
+    ap.add_argument("--tune", default="", help="comma-separated olap_set_tuning pairs for A/B runs, e.g. take_variant=5")
     args = ap.parse_args()
     import numpy as np
     from dpu_olap_amd import capi
@@ -51,6 +52,9 @@ def main():
         dist.init_process_group("gloo")   # scalars only: barrier, max time, sum of results
     ctx = capi.Context(dev_index)
     info = ctx.device_info()
+    for kv in filter(None, args.tune.split(",")):
+        k, v = kv.split("=")
+        ctx.set_tuning(k, int(v))
     sf = args.sf
     if sf % world:
         raise SystemExit(f"SF={sf} must be a multiple of the number of GPUs ({world})")

@@ -18,6 +18,7 @@
 namespace olap {
 
 constexpr int kWave = 64;  // CDNA wavefront
+constexpr uint32_t kXcds = 8;  // MI355X: workgroup i of a launch runs on XCD i % 8 (each XCD has its own L2)
 
 // ---------------------------------------------------------------- phases
 enum Phase : int {
@@ -84,7 +85,7 @@ struct olap_ctx {
   int radix_bits_total = -1;
   int max_bits_per_pass = 0;
   int scatter_variant = 0;  // 0 write-combining scatter, 1 tile-staged scatter (A/B)
-  int take_variant = 0;    // 0 auto, 1 never use the LDS-window kernel, 2 never use small tiles
+  int take_variant = 0;    // 0 auto, 1 never the LDS-window kernel, 3 small tiles, 4 the window-bucketed path
   int line16 = 0;          // 1: 128-byte write-combining lines for passes of <= 512 buckets (measured: no gain yet, the kernel is not write-bound there)
   int direct_table = 1;    // collision-free direct-address LDS table when <= 14 hash bits remain (0: always probe)
   int wc_geometry = 2;     // 2: passes of <= 512 buckets use 512-thread workgroups on 4096-tuple tiles, two per CU
@@ -285,6 +286,10 @@ __device__ __forceinline__ uint4 gload4_nt(const void* p) {
   const u32x4_t v = __builtin_nontemporal_load((const OLAP_GLOBAL u32x4_t*)p);
   return make_uint4(v.x, v.y, v.z, v.w);
 }
+__device__ __forceinline__ uint2 gload2_nt(const void* p) {
+  const u32x2_t v = __builtin_nontemporal_load((const OLAP_GLOBAL u32x2_t*)p);
+  return make_uint2(v.x, v.y);
+}
 __device__ __forceinline__ void gstore4(void* p, uint4 v) {
   u32x4_t t;
   t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
@@ -301,6 +306,26 @@ __device__ __forceinline__ void gstore2(void* p, uint2 v) {
   t.y = v.y;
   *(OLAP_GLOBAL u32x2_t*)p = t;
 }
+// any 16-byte vector type / any integer scalar through a global (not flat) access
+template <class V>
+__device__ __forceinline__ V gload_vec16(const V* p) {
+  static_assert(sizeof(V) == 16, "16-byte vectors");
+  const u32x4_t t = *(const OLAP_GLOBAL u32x4_t*)p;
+  V v;
+  __builtin_memcpy(&v, &t, 16);
+  return v;
+}
+template <class V>
+__device__ __forceinline__ void gstore_vec16(V* p, const V& v) {
+  static_assert(sizeof(V) == 16, "16-byte vectors");
+  u32x4_t t;
+  __builtin_memcpy(&t, &v, 16);
+  *(OLAP_GLOBAL u32x4_t*)p = t;
+}
+template <class T>
+__device__ __forceinline__ T gload_t(const T* p) { return *(const OLAP_GLOBAL T*)p; }
+template <class T>
+__device__ __forceinline__ void gstore_t(T* p, T v) { *(OLAP_GLOBAL T*)p = v; }
 __device__ __forceinline__ uint32_t gload1(const void* p) { return *(const OLAP_GLOBAL uint32_t*)p; }
 __device__ __forceinline__ uint64_t gload1_u64(const void* p) { return *(const OLAP_GLOBAL uint64_t*)p; }
 

@@ -69,13 +69,13 @@ __global__ __launch_bounds__(kBlock) void k_sum(ColView v, const void* const* pt
       const V* pv = (const V*)p;
       V x[kVecPerThread];
 #pragma unroll
-      for (int j = 0; j < kVecPerThread; ++j) x[j] = pv[j * kBlock + threadIdx.x];
+      for (int j = 0; j < kVecPerThread; ++j) x[j] = gload_vec16(pv + j * kBlock + threadIdx.x);
 #pragma unroll
       for (int j = 0; j < kVecPerThread; ++j)
 #pragma unroll
         for (int k = 0; k < E; ++k) acc += (ACC)vec_get<T>(x[j], k);
     } else {
-      for (uint32_t i = threadIdx.x; i < n; i += kBlock) acc += (ACC)p[i];
+      for (uint32_t i = threadIdx.x; i < n; i += kBlock) acc += (ACC)gload_t(p + i);
     }
   }
   __shared__ unsigned long long s_part[kBlock / kWave];
@@ -112,7 +112,7 @@ __device__ __forceinline__ void filter_tile_flags(const T* p, uint32_t n, uint32
     const V* pv = (const V*)p;
     V x[kVecPerThread];
 #pragma unroll
-    for (int j = 0; j < kVecPerThread; ++j) x[j] = pv[j * kBlock + threadIdx.x];
+    for (int j = 0; j < kVecPerThread; ++j) x[j] = gload_vec16(pv + j * kBlock + threadIdx.x);
 #pragma unroll
     for (int j = 0; j < kVecPerThread; ++j) {
       uint32_t f = 0;
@@ -130,7 +130,7 @@ __device__ __forceinline__ void filter_tile_flags(const T* p, uint32_t n, uint32
 #pragma unroll
       for (int k = 0; k < E; ++k) {
         uint32_t idx = (j * kBlock + threadIdx.x) * E + k;
-        T x = idx < n ? p[idx] : thr;  // thr itself never passes `x < thr`
+        T x = idx < n ? gload_t(p + idx) : thr;  // thr itself never passes `x < thr`
         val[j][k] = x;
         f |= ((idx < n && x < thr) ? 1u : 0u) << k;
       }
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(kBlock) void k_filter_compact(ColView sv, const voi
         uint64_t o = base + my_off[j] + rank[j];
 #pragma unroll
         for (int k = 0; k < E; ++k) {
-          if (flags[j] & (1u << k)) out[o++] = val[j][k];
+          if (flags[j] & (1u << k)) gstore_t(out + o++, val[j][k]);
         }
       }
       base += tile_total;
@@ -294,27 +294,27 @@ __global__ __launch_bounds__(kBlock) void k_take(ColView iv, const void* const* 
     if (n == TILE && (((uintptr_t)idx) & 15) == 0 && (((uintptr_t)out) & 15) == 0) {
       uint4 ix[kVecPerThread];
 #pragma unroll
-      for (int j = 0; j < kVecPerThread; ++j) ix[j] = ((const uint4*)idx)[j * kBlock + threadIdx.x];
+      for (int j = 0; j < kVecPerThread; ++j) ix[j] = gload4((const uint4*)idx + j * kBlock + threadIdx.x);
       T g[kVecPerThread][4];
 #pragma unroll
       for (int j = 0; j < kVecPerThread; ++j) {
-        g[j][0] = data[ix[j].x];
-        g[j][1] = data[ix[j].y];
-        g[j][2] = data[ix[j].z];
-        g[j][3] = data[ix[j].w];
+        g[j][0] = gload_t(data + ix[j].x);
+        g[j][1] = gload_t(data + ix[j].y);
+        g[j][2] = gload_t(data + ix[j].z);
+        g[j][3] = gload_t(data + ix[j].w);
       }
 #pragma unroll
       for (int j = 0; j < kVecPerThread; ++j) {
         T* o = out + (size_t)(j * kBlock + threadIdx.x) * 4;
         if constexpr (sizeof(T) == 4) {
-          *(uint4*)o = make_uint4((uint32_t)g[j][0], (uint32_t)g[j][1], (uint32_t)g[j][2], (uint32_t)g[j][3]);
+          gstore4(o, make_uint4((uint32_t)g[j][0], (uint32_t)g[j][1], (uint32_t)g[j][2], (uint32_t)g[j][3]));
         } else {
-          ((ulonglong2*)o)[0] = make_ulonglong2((uint64_t)g[j][0], (uint64_t)g[j][1]);
-          ((ulonglong2*)o)[1] = make_ulonglong2((uint64_t)g[j][2], (uint64_t)g[j][3]);
+          gstore_vec16((ulonglong2*)o, make_ulonglong2((uint64_t)g[j][0], (uint64_t)g[j][1]));
+          gstore_vec16((ulonglong2*)o + 1, make_ulonglong2((uint64_t)g[j][2], (uint64_t)g[j][3]));
         }
       }
     } else {
-      for (uint32_t i = threadIdx.x; i < n; i += kBlock) out[i] = data[idx[i]];
+      for (uint32_t i = threadIdx.x; i < n; i += kBlock) gstore_t(out + i, gload_t(data + gload1(idx + i)));
     }
   }
 }
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(kTBlock, 4) void k_take_lds(ColView dv, ColView iv,
 #pragma unroll
     for (int k = 0; k < kTIdxPerThread; ++k) {
       const uint32_t i = k * kTBlock + threadIdx.x;
-      ix[k] = i < m ? idx[i] : 0xFFFFFFFFu;
+      ix[k] = i < m ? gload1(idx + i) : 0xFFFFFFFFu;
       val[k] = 0;
     }
     const bool vec_ok = (((uintptr_t)data) & 15) == 0;
@@ -355,9 +355,9 @@ __global__ __launch_bounds__(kTBlock, 4) void k_take_lds(ColView dv, ColView iv,
       if (vec_ok && wn == W) {
         const uint4* src = (const uint4*)(data + w0);
 #pragma unroll
-        for (int j = 0; j < kTWindowBytes / 16 / kTBlock; ++j) ((uint4*)s_win)[j * kTBlock + threadIdx.x] = src[j * kTBlock + threadIdx.x];
+        for (int j = 0; j < kTWindowBytes / 16 / kTBlock; ++j) ((uint4*)s_win)[j * kTBlock + threadIdx.x] = gload4(src + j * kTBlock + threadIdx.x);
       } else {
-        for (uint32_t i = threadIdx.x; i < wn; i += kTBlock) win[i] = data[w0 + i];
+        for (uint32_t i = threadIdx.x; i < wn; i += kTBlock) win[i] = gload_t(data + w0 + i);
       }
       __syncthreads();
 #pragma unroll
@@ -369,7 +369,137 @@ __global__ __launch_bounds__(kTBlock, 4) void k_take_lds(ColView dv, ColView iv,
 #pragma unroll
     for (int k = 0; k < kTIdxPerThread; ++k) {
       const uint32_t i = k * kTBlock + threadIdx.x;
-      if (i < m) out[i] = val[k];
+      if (i < m) gstore_t(out + i, val[k]);
+    }
+  }
+}
+
+// Large batches (data buffer far beyond LDS, e.g. BM_TakeDpu's 4 Mi-row shape): a direct gather moves one
+// 128-byte L2 line per 4-byte value.  An alternative of two streaming kernels (opt-in, take_variant = 4; slower than
+// the gather on the benchmark shape, see run_take):
+//   k_take_bucket  one workgroup per batch buckets the batch's (index, position) pairs by 64 KiB window of the data
+//                  buffer (LDS histogram -> scan -> scatter of 8-byte pairs inside the batch's own pair region);
+//   k_take_window  one workgroup per (batch, window): the window is read once, coalesced, into LDS, and the
+//                  window's pairs are served from it.
+// Bytes per index: 4 (index) + 8 + 8 (pair out and back) + sizeof(T) (result) + the data buffer read once.
+constexpr int kTbBlock = 1024;
+constexpr uint32_t kTbMaxWin = 1024;  // windows per batch the bucket kernel keeps counters for
+
+// f(index value, position) over one batch's indices: two 16-byte loads in flight per thread
+template <class F>
+__device__ __forceinline__ void tb_for_each(const uint32_t* idx, uint32_t m, F&& f) {
+  const unsigned t = threadIdx.x;
+  uint32_t done = 0;
+  if ((((uintptr_t)idx) & 15) == 0) {
+    const uint4* v = (const uint4*)idx;
+    const uint32_t nvec = m >> 2;
+    uint32_t i = t;
+    for (; i + kTbBlock < nvec; i += 2 * kTbBlock) {
+      const uint4 a = gload4(v + i), b = gload4(v + i + kTbBlock);
+      f(a.x, 4 * i), f(a.y, 4 * i + 1), f(a.z, 4 * i + 2), f(a.w, 4 * i + 3);
+      const uint32_t j = 4 * (i + kTbBlock);
+      f(b.x, j), f(b.y, j + 1), f(b.z, j + 2), f(b.w, j + 3);
+    }
+    for (; i < nvec; i += kTbBlock) {
+      const uint4 a = gload4(v + i);
+      f(a.x, 4 * i), f(a.y, 4 * i + 1), f(a.z, 4 * i + 2), f(a.w, 4 * i + 3);
+    }
+    done = nvec << 2;
+  }
+  for (uint32_t i = done + t; i < m; i += kTbBlock) f(gload1(idx + i), i);
+}
+
+__global__ __launch_bounds__(kTbBlock) void k_take_bucket(ColView iv, ColView dv, uint32_t nb,
+                                                          const void* const* idx_ptrs, uint32_t wshift,
+                                                          uint32_t nwin_max, uint2* pairs, uint32_t* win_off) {
+  __shared__ uint32_t s_cnt[kTbMaxWin];
+  __shared__ uint32_t s_wave[kTbBlock / kWave];
+  const unsigned t = threadIdx.x, lane = lane_id(), wave = t / kWave;
+  for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
+    const uint32_t m = (uint32_t)batch_rows(iv, b);
+    const uint64_t rows = batch_rows(dv, b);
+    const uint32_t last = rows ? (uint32_t)((rows - 1) >> wshift) : 0;  // last window, < nwin_max (host)
+    const uint32_t* idx = (const uint32_t*)idx_ptrs[b];
+    uint2* pr = pairs + batch_row0(iv, b);
+    uint32_t* off = win_off + (uint64_t)b * (nwin_max + 1);
+    s_cnt[t] = 0;
+    __syncthreads();
+    tb_for_each(idx, m, [&](uint32_t ix, uint32_t) { atomicAdd(&s_cnt[min(ix >> wshift, last)], 1u); });
+    __syncthreads();
+    // exclusive scan of the counters (thread t owns window t)
+    const uint32_t c = s_cnt[t];
+    uint32_t incl = c;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+      const uint32_t up = __shfl_up(incl, o, kWave);
+      if ((int)lane >= o) incl += up;
+    }
+    if (lane == kWave - 1) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t excl = incl - c;
+    for (unsigned w = 0; w < wave; ++w) excl += s_wave[w];
+    s_cnt[t] = excl;  // now the window's cursor
+    if (t < nwin_max) off[t] = t <= last ? excl : m;
+    if (t == 0) off[nwin_max] = m;
+    __syncthreads();
+    tb_for_each(idx, m, [&](uint32_t ix, uint32_t pos) {
+      const uint32_t slot = atomicAdd(&s_cnt[min(ix >> wshift, last)], 1u);
+      gstore2(pr + slot, make_uint2(ix, pos));
+    });
+    __syncthreads();
+  }
+}
+
+// Work item = (batch, window).  The scattered 4-byte result stores of one batch must meet in ONE L2 to leave it as
+// whole lines (measured: spread over the 8 XCDs they reach HBM as 32-byte partial writes, 8x the bytes), so batch b
+// belongs to XCD b % 8 -- workgroups are dealt to the XCDs round-robin by blockIdx -- and the streams that pass
+// through (window, pairs) are loaded non-temporal so they do not push the half-written result lines out.
+template <typename T>
+__global__ __launch_bounds__(kTBlock, 4) void k_take_window(ColView dv, ColView iv, uint32_t nb, uint32_t wshift,
+                                                            uint32_t nwin_max, const void* const* data_ptrs,
+                                                            const uint2* pairs, const uint32_t* win_off,
+                                                            void* const* out_ptrs) {
+  __shared__ __attribute__((aligned(16))) unsigned char s_win[kTWindowBytes];
+  constexpr uint32_t W = kTWindowBytes / sizeof(T);  // elements per window = 1 << wshift
+  constexpr int kQ = 4;                              // pairs in flight per thread
+  T* win = reinterpret_cast<T*>(s_win);
+  const uint32_t xcd = blockIdx.x % kXcds, slot = blockIdx.x / kXcds, nslots = gridDim.x / kXcds;  // gridDim % 8 == 0
+  const uint32_t my_batches = nb > xcd ? (nb - xcd + kXcds - 1) / kXcds : 0;
+  const uint64_t items = (uint64_t)my_batches * nwin_max;
+  for (uint64_t item = slot; item < items; item += nslots) {
+    const uint32_t b = (uint32_t)(item / nwin_max) * kXcds + xcd, w = (uint32_t)(item % nwin_max);
+    const uint32_t* off = win_off + (uint64_t)b * (nwin_max + 1) + w;
+    const uint32_t lo = off[0], hi = off[1];
+    if (lo == hi) continue;  // nobody asked for this window (uniform across the workgroup)
+    const uint64_t rows = batch_rows(dv, b);
+    const uint32_t w0 = w << wshift;
+    const uint32_t wn = (uint32_t)min((uint64_t)W, rows - w0);
+    const T* data = (const T*)data_ptrs[b] + w0;
+    const uint2* pr = pairs + batch_row0(iv, b);
+    T* out = (T*)out_ptrs[b];
+    uint2 q[kQ];  // the first pairs travel together with the window
+#pragma unroll
+    for (int k = 0; k < kQ; ++k) q[k] = gload2_nt(pr + min(lo + k * kTBlock + threadIdx.x, hi - 1));
+    __syncthreads();  // previous window fully consumed
+    if (wn == W && (((uintptr_t)data) & 15) == 0) {
+#pragma unroll
+      for (int j = 0; j < kTWindowBytes / 16 / kTBlock; ++j)
+        ((uint4*)s_win)[j * kTBlock + threadIdx.x] = gload4_nt((const uint4*)data + j * kTBlock + threadIdx.x);
+    } else {
+      for (uint32_t i = threadIdx.x; i < wn; i += kTBlock) win[i] = gload_t(data + i);
+    }
+    __syncthreads();
+    for (uint32_t p0 = lo;;) {
+#pragma unroll
+      for (int k = 0; k < kQ; ++k) {
+        const uint32_t rel = q[k].x - w0;
+        // an index beyond the batch reads as 0, like the LDS kernel
+        if (p0 + k * kTBlock + threadIdx.x < hi) gstore_t(out + q[k].y, rel < wn ? win[rel] : (T)0);
+      }
+      p0 += kQ * kTBlock;
+      if (p0 >= hi) break;
+#pragma unroll
+      for (int k = 0; k < kQ; ++k) q[k] = gload2_nt(pr + min(p0 + k * kTBlock + threadIdx.x, hi - 1));
     }
   }
 }
@@ -582,16 +712,27 @@ static int run_take(olap_ctx* ctx, const void* const* data_ptrs, const uint64_t*
                     column_set_bytes(idx_rows + b0, cnt, 1, &ib, in_mem) + align_up(cnt * 8, 256) + 8192;
     if (out_mem == OLAP_MEM_HOST)
       for (uint64_t b = b0; b < b1; ++b) need += align_up(idx_rows[b] * eb, 256);
-    OLAP_TRY(pinned_begin(ctx, (cnt + 1) * 8 * 8 + 4096));
-    OLAP_TRY(ws_begin(ctx, need));
     // choose the kernel by batch shape
-    uint64_t max_data = 0, max_idx = 0;
+    uint64_t max_data = 0, max_idx = 0, sum_data = 0, sum_idx = 0;
     for (uint64_t b = b0; b < b1; ++b) {
       if (data_rows[b] > max_data) max_data = data_rows[b];
       if (idx_rows[b] > max_idx) max_idx = idx_rows[b];
+      sum_data += data_rows[b];
+      sum_idx += idx_rows[b];
     }
     const bool lds_path = ctx->take_variant != 1 && max_idx <= (uint64_t)kTBlock * kTIdxPerThread &&
                           max_data * eb <= 8ull * kTWindowBytes && cnt >= (uint64_t)ctx->compute_units;
+    // window-bucketed path (take_variant = 4 only): reads the data buffers once (sum_data * eb) plus ~24 B per index
+    // instead of one 128-byte line per index -- and loses: at SF=2048 (2048 x 4 Mi rows, 512 Ki indices each) it takes
+    // 6.9 + 17.6 ms against 20-22 ms for the direct gather, because the scattered 4-byte result stores leave the L2
+    // as 32-byte partial writes (WRITE_SIZE 38.5 GB for 4.3 GB of results), with or without keeping a batch on one
+    // XCD.  Kept as a tested alternative; profiles/r2_ab_experiments.md has the numbers.
+    const uint32_t wshift = eb == 4 ? 14 : 13;  // 64 KiB windows
+    const uint64_t nwin_max = max_data ? ((max_data - 1) >> wshift) + 1 : 1;
+    const bool bucket_path = ctx->take_variant == 4 && !lds_path && nwin_max <= kTbMaxWin && max_idx < (1ull << 32) && sum_idx > 0;
+    if (bucket_path) need += align_up(sum_idx * 8, 256) + align_up(cnt * (nwin_max + 1) * 4, 256);
+    OLAP_TRY(pinned_begin(ctx, (cnt + 1) * 8 * 8 + 4096));
+    OLAP_TRY(ws_begin(ctx, need));
     // large batches, experiment knob (take_variant = 3): small tiles keep fewer batches in
     // flight; measured no gain at SF=2048 -- the 64-B random gathers already move a whole
     // 128-B L2 line each (2^30 gathers in 21.9 ms = 6.3 TB/s of lines), so this stays off.
@@ -616,7 +757,17 @@ static int run_take(olap_ctx* ctx, const void* const* data_ptrs, const uint64_t*
     OLAP_HIP(ctx, hipMemcpyAsync(d_out_tbl, h_out, (cnt ? cnt : 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     if (is.view.total_units) {
       PhaseScope ps(ctx, PH_TAKE);
-      if (lds_path) {
+      if (bucket_path) {
+        uint2* d_pairs = (uint2*)ws_alloc(ctx, sum_idx * 8);
+        uint32_t* d_win_off = (uint32_t*)ws_alloc(ctx, cnt * (nwin_max + 1) * 4);
+        if (!d_pairs || !d_win_off) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (take pairs)");
+        hipLaunchKernelGGL(k_take_bucket, dim3(grid_for(ctx, cnt, 1)), dim3(kTbBlock), 0, ctx->stream, is.view, ds.view,
+                           (uint32_t)cnt, is.dev_ptr_tables[0], wshift, (uint32_t)nwin_max, d_pairs, d_win_off);
+        const int wgrid = (int)align_up((uint64_t)grid_for(ctx, cnt * nwin_max, 2), kXcds);
+        hipLaunchKernelGGL((k_take_window<T>), dim3(wgrid), dim3(kTBlock), 0, ctx->stream, ds.view, is.view, (uint32_t)cnt,
+                           wshift, (uint32_t)nwin_max, ds.dev_ptr_tables[0], (const uint2*)d_pairs,
+                           (const uint32_t*)d_win_off, (void* const*)d_out_tbl);
+      } else if (lds_path) {
         hipLaunchKernelGGL((k_take_lds<T>), dim3(grid_for(ctx, cnt, 2)), dim3(kTBlock), 0, ctx->stream, ds.view, is.view,
                            (uint32_t)cnt, ds.dev_ptr_tables[0], is.dev_ptr_tables[0], (void* const*)d_out_tbl);
       } else if (small_tiles) {

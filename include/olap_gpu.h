@@ -288,7 +288,8 @@ int olap_join_configure(olap_ctx* ctx, int radix_bits_total, int max_bits_per_pa
  *                      | 0 the write-combining kernels
  *   ring_tpt           8 (default) | 4 tuples per producer thread and tile of the ring scatter
  *   direct_table       1 direct-address LDS table when <= 14 hash bits remain (default) | 0 probing table
- *   take_variant       0 automatic | 1 never the LDS-window kernel | 2 never small tiles
+ *   take_variant       0 automatic | 1 never the LDS-window kernel | 3 small gather tiles | 4 window-bucketed path
+ *                      for batches whose data buffer is far larger than LDS (an alternative that measured slower)
  *   host_stage         1 pinned ring + copy threads for OLAP_MEM_HOST operands (default) | 0 plain hipMemcpyAsync
  *   host_copy_threads  0 = min(hardware threads, 8) */
 int olap_set_tuning(olap_ctx* ctx, const char* key, int value);

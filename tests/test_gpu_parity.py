@@ -781,6 +781,62 @@ def test_take_large_batches_small_tile_kernel(dev):
             np.testing.assert_array_equal(dev.to_host(res[b]), oracle.take(data[b], idx[b]))
 
 
+@pytest.mark.parametrize("t", ["u32", "i32", "u64", "i64"])
+def test_take_window_bucketed_path(dev, t):
+    """Batches whose data buffer is far beyond LDS: indices bucketed by 64 KiB window, windows served from LDS
+    (take_variant 4 selects the path; it is opt-in because the direct gather is faster on the MI355X).  Ragged data sizes
+    (partial last window, one-row buffer, exactly one window, unaligned device slices), ragged and empty index
+    batches, duplicate and clustered indices; compared with the oracle, as is the direct gather (variant 0)."""
+    o = _ops()
+    rng = np.random.default_rng(1234)
+    dt = TYPES[t]
+    win = (64 << 10) // np.dtype(dt).itemsize
+    nb = 144
+    rows = [5 * win + 77] * nb
+    rows[0], rows[1], rows[2], rows[3], rows[4] = 1, win, win + 1, 37 * win - 5, 2 * win
+    data = [rng.integers(0, 1 << 31, size=r, dtype=np.int64).astype(dt) for r in rows]
+    idx = [rng.integers(0, r, size=40000 + 13 * (b % 7), dtype=np.uint32) for b, r in enumerate(rows)]
+    idx[5] = idx[5][:0]
+    idx[6] = idx[6][:1]
+    idx[7] = np.full(5000, rows[7] - 1, dtype=np.uint32)                         # one window, one element
+    idx[8] = np.sort(idx[8])                                                       # clustered
+    idx[9] = (np.arange(30000, dtype=np.uint32) * 7) % np.uint32(rows[9])
+    # unaligned device buffers: slices of a larger allocation, off by one element
+    keep = []
+
+    def shifted(a, name):
+        whole = dev.to_device(np.concatenate([a[:1], a]))
+        keep.append(whole)
+        return o.DeviceArray(whole.ptr + a.itemsize, a.size, name)
+
+    d_data = [shifted(d, np.dtype(dt).name) if b % 3 == 1 else dev.to_device(d) for b, d in enumerate(data)]
+    d_idx = [shifted(i, "uint32") if b % 4 == 2 and i.size else dev.to_device(i) for b, i in enumerate(idx)]
+    want = [oracle.take(d, i) for d, i in zip(data, idx)]
+    for variant in (4, 0):
+        dev.set_tuning("take_variant", variant)
+        try:
+            res = o.TakeGpu(dev, d_data, d_idx).Prepare().Run()
+        finally:
+            dev.set_tuning("take_variant", 0)
+        for b in range(nb):
+            np.testing.assert_array_equal(dev.to_host(res[b]), want[b], err_msg=f"variant {variant} batch {b}")
+
+
+def test_take_window_bucketed_host_operands(dev):
+    """The same path with OLAP_MEM_HOST operands and results (staged through the arena)."""
+    o = _ops()
+    rng = np.random.default_rng(77)
+    data = [rng.integers(0, 1 << 32, size=(1 << 18) + 5 * b, dtype=np.uint32) for b in range(6)]
+    idx = [rng.integers(0, d.size, size=50000 + b, dtype=np.uint32) for b, d in enumerate(data)]
+    dev.set_tuning("take_variant", 4)
+    try:
+        res = o.TakeGpu(dev, data, idx).Prepare().Run()
+    finally:
+        dev.set_tuning("take_variant", 0)
+    for b in range(6):
+        np.testing.assert_array_equal(np.asarray(res[b]), oracle.take(data[b], idx[b]))
+
+
 # ------------------------------------------------------- host staging ring
 @pytest.mark.parametrize("stage,threads", [(1, 0), (1, 1), (1, 3), (0, 0)])
 def test_host_operands_through_the_pinned_ring(dev, stage, threads):
