@@ -148,7 +148,8 @@ static uint32_t claim_cap(const olap_ctx* ctx, uint64_t rows, uint64_t F) {
   const uint64_t avg = (rows + F - 1) / F;
   uint64_t sd = 1;
   while (sd * sd < avg) ++sd;
-  const uint64_t cap = align_up(avg + avg / 64 + 8 * sd + (kb + 2) * kClaimChunk, kClaimChunk);
+  // woven regions (ring scatter, radix_kernels.h woven_at): whole chunks
+  const uint64_t cap = align_up(avg + avg / 64 + 8 * sd + (kb + 2) * kClaimChunk, ring && ctx->claim_weave ? (1ull << kWeaveShift) : kClaimChunk);
   return cap >= (1ull << 32) ? 0u : (uint32_t)cap;
 }
 
@@ -395,18 +396,22 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
     if (blocks > 0x7FFFFFFFull) return ctx->fail(OLAP_ERR_INVALID, "partition grid too large");
     if (claim_pass) {
       const uint32_t ccap = claim_cap(ctx, rows, F);
+      const bool weave = ring_claim && ctx->claim_weave && ccap % (1u << kWeaveShift) == 0;
       uint32_t* cursor = (uint32_t*)ws_alloc(ctx, F * 4);
       if (!cursor || !ccap) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (claim cursors)");
       OLAP_HIP(ctx, hipMemsetAsync(cursor, 0, F * 4, ctx->stream));
       {
         PhaseScope ps(ctx, PH_PART_SCATTER_CLAIM);
-        const ClaimOut co{ccap, cursor, d_overflow};
+        const ClaimOut co{ccap, cursor, d_overflow, weave ? kWeaveShift : 0u, (uint32_t)(n_seg * F)};
+
         if (ring_claim) OLAP_TRY(launch_ring(ctx, cols, true, (unsigned)blocks, src, shift, fbits, out, CapOut{}, co));
         else OLAP_TRY(launch_claim(ctx, cols, g2, (unsigned)blocks, src, shift, fbits, out, co));
         OLAP_HIP(ctx, hipGetLastError());
       }
       src.seg_cnt = cursor;  // the next pass reads regions of `ccap` tuples and skips the fillers
       src.seg_cap = ccap;
+      src.weave_shift = weave ? kWeaveShift : 0u;
+      src.weave_n = (uint32_t)(n_seg * F);
       src.chk_shift = shift;
       src.chk_mask = (uint32_t)F - 1;
       claimed_input = true;
@@ -768,6 +773,10 @@ int olap_set_tuning(olap_ctx* ctx, const char* key, int value) {
   if (!std::strcmp(key, "ring_scatter")) {
     if (value < 0 || value > 3) return ctx->fail(OLAP_ERR_INVALID, "ring_scatter must be 0 (off), 1 (claiming pass), 2 (capacity pass) or 3 (both)");
     ctx->ring_scatter = value;
+    return OLAP_OK;
+  }
+  if (!std::strcmp(key, "claim_weave")) {
+    ctx->claim_weave = value != 0;
     return OLAP_OK;
   }
   if (!std::strcmp(key, "ring_interleave")) {

@@ -56,6 +56,9 @@ struct PassSrc {
   uint32_t seg_cap;
   uint32_t chk_shift;
   uint32_t chk_mask;  // 0: every tuple in range is real
+  // ... in the WOVEN layout (weave_shift != 0, see woven_at): tuple p of segment k lies at woven_at(k, p, ...)
+  uint32_t weave_shift;
+  uint32_t weave_n;
   // Bucket ORDER of a single-pass split (olap_split_tuples_u32): the bucket id read from the hash is
   // [owner | group | low] (ord_owner_bits, ord_group_bits, ord_low_bits wide); it is emitted as
   // [group | owner | low], so that everything a sub-bucket group sends to all owners is one contiguous run.
@@ -74,6 +77,19 @@ __device__ __forceinline__ uint32_t pass_bucket(const PassSrc& s, uint32_t h, ui
     b = (grp << (s.ord_owner_bits + s.ord_low_bits)) | (own << s.ord_low_bits) | low;
   }
   return b;
+}
+
+// Woven regions of the claiming scatter.  Laid out one after the other, the F regions of pass 0 are 64 MiB apart at
+// 2^32 rows, and every workgroup writes one 128-byte line to each of them in turn: every line store misses the CU's
+// address-translation cache (rocprofv3: TCP_UTCL1_TRANSLATION_MISS = 2.9e8 per launch, one per line; the same kernel
+// writing inside ONE region: 2.5e3).  Woven, the regions are cut into chunks of 2^weave_shift tuples and chunk c of region
+// k lies at ((c * n_regions) + k) chunks: all regions fill at the same pace (uniform hash, global cursors), so at any
+// moment the whole chip writes inside a window of about n_regions chunks (32 MiB), and the reader of region k takes one
+// chunk-sized stride per 64 KiB it reads.  A tile (2048 / 4096 / 8192 tuples) never straddles a chunk.
+constexpr uint32_t kWeaveShift = 13;  // 8192 tuples = 64 KiB per chunk
+__device__ __forceinline__ uint64_t woven_at(uint64_t region, uint64_t p, uint32_t cap, uint32_t weave_shift, uint32_t n_regions) {
+  if (!weave_shift) return region * cap + p;
+  return ((((p >> weave_shift) * n_regions) + region) << weave_shift) + (p & ((1ull << weave_shift) - 1ull));
 }
 
 struct TileRange {
@@ -219,8 +235,11 @@ __device__ __forceinline__ uint32_t load_tile(const PassSrc& s, const TileRange&
     }
   } else {
     const uint64_t base = r.a + tile * (uint64_t)TILE;
+    // woven input (claimed regions: r.a == r.lo == seg * seg_cap): where the tile's first tuple really lies
+    const uint2* tuples = s.tuples;
+    if (s.weave_shift) tuples += (int64_t)(woven_at(r.seg, tile * (uint64_t)TILE, s.seg_cap, s.weave_shift, s.weave_n) - base);
     if (base >= r.lo && base + TILE <= r.hi) {  // whole tile inside the segment (uniform)
-      const uint4* tv = (const uint4*)(s.tuples + base);
+      const uint4* tv = (const uint4*)(tuples + base);
 #pragma unroll
       for (int j = 0; j < TPT / 2; ++j) {
         const uint4 t = NT ? gload4_nt(tv + j * BLOCK + threadIdx.x) : tv[j * BLOCK + threadIdx.x];
@@ -236,9 +255,9 @@ __device__ __forceinline__ uint32_t load_tile(const PassSrc& s, const TileRange&
       const uint64_t i0 = base + (uint64_t)(j * BLOCK + threadIdx.x) * 2;
       uint4 t = make_uint4(0, 0, 0, 0);
       if (i0 + 1 < r.hi) {
-        t = *(const uint4*)(s.tuples + i0);
+        t = *(const uint4*)(tuples + i0);
       } else if (i0 < r.hi) {  // last, odd tuple: never read past the end of a caller's array
-        const uint2 t1 = s.tuples[i0];
+        const uint2 t1 = tuples[i0];
         t.x = t1.x;
         t.y = t1.y;
       }
@@ -678,6 +697,8 @@ struct ClaimOut {
   uint32_t cap;      // tuples per region, multiple of kClaimChunk
   uint32_t* cursor;  // [n_seg * F], zeroed before the launch: tuples claimed per region
   unsigned long long* overflow;
+  uint32_t weave_shift;  // != 0: woven regions (woven_at; cap is then a multiple of the chunk); ring scatter only
+  uint32_t weave_n;      // n_seg * F
 };
 #ifndef OLAP_CLAIM_CHUNK
 #define OLAP_CLAIM_CHUNK 128

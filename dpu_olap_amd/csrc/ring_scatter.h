@@ -101,6 +101,9 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring(PassSrc s, uint32_t
   const unsigned wave = threadIdx.x / kWave;
   const uint32_t cap = CLAIM ? cq.cap : co.cap;
   unsigned long long* const overflow = CLAIM ? cq.overflow : co.overflow;
+  // where tuple p of output region `region` lies (CLAIM: possibly woven regions, radix_kernels.h woven_at)
+  const uint32_t wv_shift = CLAIM ? cq.weave_shift : 0u, wv_n = CLAIM ? cq.weave_n : 0u;
+  auto at = [&](uint64_t region, uint32_t p) { return woven_at(region, p, cap, wv_shift, wv_n); };
   for (uint32_t b = threadIdx.x; b < FMAX + C::kDummy; b += BLOCK) cl[b] = 0;
   if (CLAIM) {
     for (uint32_t b = threadIdx.x; b < FMAX; b += BLOCK) {
@@ -184,7 +187,7 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring(PassSrc s, uint32_t
             const uint2 info = hot[b];
             const uint32_t full = info.y & 0xFFFFu, hd = info.y >> 16, sl = v[i] & 0xFFFFu;
             if (sl < full) {  // goes straight to the range the owner reserved (dropped when the region is full)
-              if (info.x != kRingNone) gstore2(out + ((uint64_t)r.seg * F + b) * cap + info.x + (sl - kRing), make_uint2(c.key[i], c.pay[i]));
+              if (info.x != kRingNone) gstore2(out + at((uint64_t)r.seg * F + b, info.x + (sl - kRing)), make_uint2(c.key[i], c.pay[i]));
             } else {          // tail of the tile: the bucket's new residue
               ring[b * kRing + ((hd + (sl - full)) & (kRing - 1))] = make_uint2(c.key[i], c.pay[i]);
             }
@@ -211,7 +214,6 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring(PassSrc s, uint32_t
     const uint32_t b_own = fw * bpw + lane;
     const bool owner = lane < bpw && b_own < F;
     const uint64_t p_own = (uint64_t)r.seg * F + b_own;
-    const uint32_t line0 = (uint32_t)(p_own * cap / LINE);  // first line of the bucket's region (cap is a multiple of LINE)
     uint2* list = (uint2*)(smem + C::kList) + fw * kWave;
     uint32_t pos = 0, rem = 0;                   // next line's tuple offset in the region; CLAIM: tuples left in the allotment
     uint32_t fill_lo = 0, fill_hi = 0;           // CLAIM: unused tail of a hot tile's block
@@ -250,7 +252,7 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring(PassSrc s, uint32_t
       const unsigned long long m = __ballot(has);
       if (!m) return false;
       const uint32_t n = (uint32_t)__popcll(m);
-      if (has) list[__popcll(m & ((1ull << lane) - 1ull))] = make_uint2(line0 + d / LINE, b_own * kRing + ring_line);
+      if (has) list[__popcll(m & ((1ull << lane) - 1ull))] = make_uint2((uint32_t)(at(p_own, d) / LINE), b_own * kRing + ring_line);  // line index: < 2^32 (cap, chunks: multiples of LINE)
       __builtin_amdgcn_wave_barrier();
       for (uint32_t k = 0; k < n; k += LPI) {
         const uint32_t j = k + lane / LPL;
@@ -298,15 +300,31 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring(PassSrc s, uint32_t
           uint32_t dbase = kRingNone;
           if (nd && !dead) {
             if (CLAIM) {
-              const uint32_t blk = (nd + kClaimChunk - 1) / kClaimChunk * kClaimChunk;
-              const uint32_t got = atomicAdd(&cq.cursor[p_own], blk);
-              if ((uint64_t)got + blk > cap) {
-                dead = true;
-                atomicAdd(overflow, 1ull);
-              } else {
-                dbase = got;
-                fill_lo = got + nd;
-                fill_hi = got + blk;
+              // nd is a multiple of LINE.  Normally it comes out of the allotment in use, or -- what is left of that one
+              // padded with fillers -- out of the reserve: no atomic to wait for (some bucket is hot in most tiles at 512
+              // buckets: a block claimed on the spot cost a round trip to the cursor per tile).
+              if (nd <= kClaimChunk) {
+                if (rem < nd) {
+                  fill_lo = pos;
+                  fill_hi = pos + rem;
+                  next_allotment();
+                }
+                if (!dead) {
+                  dbase = pos;
+                  pos += nd;
+                  rem -= nd;
+                }
+              } else {  // a very hot bucket: its own block
+                const uint32_t blk = (nd + kClaimChunk - 1) / kClaimChunk * kClaimChunk;
+                const uint32_t got = atomicAdd(&cq.cursor[p_own], blk);
+                if ((uint64_t)got + blk > cap) {
+                  dead = true;
+                  atomicAdd(overflow, 1ull);
+                } else {
+                  dbase = got;
+                  fill_lo = got + nd;
+                  fill_hi = got + blk;
+                }
               }
             } else if ((uint64_t)pos + nd > cap) {
               dead = true;
@@ -325,7 +343,7 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring(PassSrc s, uint32_t
       __syncthreads();  // ---- barrier 2
       if (misc[0] == (uint32_t)tile + 1u) {
         if (CLAIM) {
-          for (uint32_t q = fill_lo; q < fill_hi; q += 2) *(uint4*)(out + p_own * cap + q) = make_uint4(filler, 0u, filler, 0u);
+          for (uint32_t q = fill_lo; q < fill_hi; q += 2) *(uint4*)(out + at(p_own, q)) = make_uint4(filler, 0u, filler, 0u);
           fill_lo = fill_hi = 0;
         }
         __syncthreads();  // ---- barrier 3 (hot tiles only)
@@ -336,23 +354,24 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring(PassSrc s, uint32_t
     if (owner) {
       const uint32_t vv = cl[b_own];
       const uint32_t rr = vv & 0xFFFFu, hd = vv >> 16;
-      uint2* region = out + p_own * cap;
+      uint2* region = out + p_own * cap;  // (capacity layout; a claimed allotment is addressed through at())
       if (CLAIM) {
         if (!dead && rr) {
           if (rem == 0) next_allotment();
           if (!dead) {  // the residue as one line padded with fillers
+            uint2* line = out + at(p_own, pos);
             for (uint32_t j = 0; j < (uint32_t)LINE; ++j)
-              region[pos + j] = j < rr ? ring[b_own * kRing + ((hd + j) & (kRing - 1))] : make_uint2(filler, 0u);
+              line[j] = j < rr ? ring[b_own * kRing + ((hd + j) & (kRing - 1))] : make_uint2(filler, 0u);
             pos += LINE;
             rem -= LINE;
           }
         }
         if (!dead) {  // the rest of the allotment, and the one claimed ahead, hold only fillers
-          for (uint32_t q = 0; q < rem; q += 2) *(uint4*)(region + pos + q) = make_uint4(filler, 0u, filler, 0u);
+          for (uint32_t q = 0; q < rem; q += 2) *(uint4*)(out + at(p_own, pos + q)) = make_uint4(filler, 0u, filler, 0u);
         }
         const uint32_t ahead = rsv[b_own];
         if (ahead != kRingNone && (uint64_t)ahead + kClaimChunk <= cap)
-          for (uint32_t q = 0; q < kClaimChunk; q += 2) *(uint4*)(region + ahead + q) = make_uint4(filler, 0u, filler, 0u);
+          for (uint32_t q = 0; q < kClaimChunk; q += 2) *(uint4*)(out + at(p_own, ahead + q)) = make_uint4(filler, 0u, filler, 0u);
       } else {
         uint32_t count = pos;
         if (!dead) {

@@ -375,7 +375,7 @@ __global__ __launch_bounds__(kTBlock, 4) void k_take_lds(ColView dv, ColView iv,
 }
 
 // Large batches (data buffer far beyond LDS, e.g. BM_TakeDpu's 4 Mi-row shape): a direct gather moves one
-// 128-byte L2 line per 4-byte value.  An alternative of two streaming kernels (opt-in, take_variant = 4; slower than
+// 64-byte sector per 4-byte value.  An alternative of two streaming kernels (opt-in, take_variant = 4; slower than
 // the gather on the benchmark shape, see run_take):
 //   k_take_bucket  one workgroup per batch buckets the batch's (index, position) pairs by 64 KiB window of the data
 //                  buffer (LDS histogram -> scan -> scatter of 8-byte pairs inside the batch's own pair region);
@@ -723,7 +723,7 @@ static int run_take(olap_ctx* ctx, const void* const* data_ptrs, const uint64_t*
     const bool lds_path = ctx->take_variant != 1 && max_idx <= (uint64_t)kTBlock * kTIdxPerThread &&
                           max_data * eb <= 8ull * kTWindowBytes && cnt >= (uint64_t)ctx->compute_units;
     // window-bucketed path (take_variant = 4 only): reads the data buffers once (sum_data * eb) plus ~24 B per index
-    // instead of one 128-byte line per index -- and loses: at SF=2048 (2048 x 4 Mi rows, 512 Ki indices each) it takes
+    // instead of one 64-byte sector per index -- and loses: at SF=2048 (2048 x 4 Mi rows, 512 Ki indices each) it takes
     // 6.9 + 17.6 ms against 20-22 ms for the direct gather, because the scattered 4-byte result stores leave the L2
     // as 32-byte partial writes (WRITE_SIZE 38.5 GB for 4.3 GB of results), with or without keeping a batch on one
     // XCD.  Kept as a tested alternative; profiles/r2_ab_experiments.md has the numbers.
@@ -734,8 +734,8 @@ static int run_take(olap_ctx* ctx, const void* const* data_ptrs, const uint64_t*
     OLAP_TRY(pinned_begin(ctx, (cnt + 1) * 8 * 8 + 4096));
     OLAP_TRY(ws_begin(ctx, need));
     // large batches, experiment knob (take_variant = 3): small tiles keep fewer batches in
-    // flight; measured no gain at SF=2048 -- the 64-B random gathers already move a whole
-    // 128-B L2 line each (2^30 gathers in 21.9 ms = 6.3 TB/s of lines), so this stays off.
+    // flight; measured no gain at SF=2048 -- every random gather moves a whole 64-byte sector
+    // (2^30 gathers in 21.9 ms = 49 G sectors/s, the random-sector rate of the memory), so this stays off.
     const bool small_tiles = !lds_path && max_data * eb > (1ull << 20) && ctx->take_variant == 3;
     const uint32_t tile_sel = small_tiles ? kBlock * 4 : TILE;
     ColumnSet ds, is;

@@ -4,6 +4,8 @@
 set -u
 OUT=gpurun_out
 TAG=${1:-r2}
+ONLY=${PMC_ONLY:-}          # e.g. PMC_ONLY="3" runs only the third counter set
+BENCH_ARGS=${BENCH_ARGS:-}  # e.g. BENCH_ARGS="--tune claim_weave=0"
 export TMPDIR=/tmp
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
@@ -13,7 +15,8 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_STALL_sum" \
            "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --output-format csv -d $OUT/pmc_${TAG}_$i -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/pmc_${TAG}_$i.log 2>&1 || { echo "pass $i failed"; tail -3 $OUT/pmc_${TAG}_$i.log; }
+  if [ -n "$ONLY" ] && [[ " $ONLY " != *" $i "* ]]; then continue; fi
+  rocprofv3 --pmc $set --output-format csv -d $OUT/pmc_${TAG}_$i -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline $BENCH_ARGS > $OUT/pmc_${TAG}_$i.log 2>&1 || { echo "pass $i failed"; tail -3 $OUT/pmc_${TAG}_$i.log; }
 done
 python3 - <<PY
 import csv, glob, collections, re
