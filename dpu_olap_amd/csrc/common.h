@@ -91,6 +91,8 @@ struct olap_ctx {
   int wc_geometry = 2;     // 2: passes of <= 512 buckets use 512-thread workgroups on 4096-tuple tiles, two per CU
   int capacity_mode = 1;   // last radix pass without histogram (fixed-capacity regions + exact fallback)
   int ring_scatter = 3;    // bit 0: claiming pass, bit 1: capacity pass: passes of <= 512 buckets run the ring scatter (ring_scatter.h): 128-byte lines, one workgroup per CU
+  int probe_run = 1;       // direct-table probe: consecutive partitions per workgroup turn
+  int ring_full_tiles = 1; // ring scatter from columns: the straight-line loader when all batches are whole aligned tiles
   int claim_weave = 1;     // claiming ring scatter writes woven regions (radix_kernels.h woven_at)
   int ring_interleave = 0; // ring scatter from columns: tiles dealt to the workgroups round-robin in chunks of this many (0: one contiguous run each)
   int ring_tpt = 8;        // tuples per producer thread and tile of the ring scatter (8: 4096-tuple tiles, 4: 2048)
@@ -183,6 +185,7 @@ struct ColView {
 struct ColumnSet {
   ColView view{};
   std::vector<const void* const*> dev_ptr_tables;  // one device pointer table per column
+  bool full_units = false;  // every batch is a whole number of units and every buffer is 16-byte aligned
 };
 
 // Builds view tables in the arena.  `cols` = ncols arrays of nb host-side pointers.

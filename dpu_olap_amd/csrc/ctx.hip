@@ -173,6 +173,8 @@ int build_column_set(olap_ctx* ctx, const void* const* const* cols, int ncols,
   v.units_per_batch = uniform ? (uint32_t)((rows[0] + unit_rows - 1) / unit_rows) : 0;
   v.uniform_rows = uniform ? (uint32_t)rows[0] : 0;
   out->dev_ptr_tables.clear();
+  bool full = nb > 0;
+  for (uint64_t b = 0; b < nb; ++b) full = full && rows[b] % unit_rows == 0;
   for (int c = 0; c < ncols; ++c) {
     const void** h_ptrs = (const void**)pinned_alloc(ctx, (nb ? nb : 1) * 8);
     const void** d_ptrs = (const void**)ws_alloc(ctx, (nb ? nb : 1) * 8);
@@ -202,9 +204,11 @@ int build_column_set(olap_ctx* ctx, const void* const* const* cols, int ncols,
         h_ptrs[b] = cols[c][b];
       }
     }
+    for (uint64_t b = 0; b < nb; ++b) full = full && (((uintptr_t)h_ptrs[b]) & 15) == 0;
     OLAP_HIP(ctx, hipMemcpyAsync(d_ptrs, h_ptrs, (nb ? nb : 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     out->dev_ptr_tables.push_back((const void* const*)d_ptrs);
   }
+  out->full_units = full;
   return OLAP_OK;
 }
 

@@ -243,25 +243,28 @@ static int launch_claim(olap_ctx* ctx, bool cols, bool g2, unsigned blocks, cons
 }
 
 // ring scatter: claiming pass (CLAIM) or capacity-layout pass, 1024 threads, one workgroup per CU
-template <int SRC, bool CLAIM, int TPT>
+template <int SRC, bool CLAIM, int TPT, int FULL = 0>
 static int launch_ring_as(olap_ctx* ctx, unsigned blocks, const PassSrc& src, uint32_t shift, uint32_t fbits, uint2* out, const CapOut& co,
                           const ClaimOut& cq) {
   constexpr uint32_t kLds = RingCfg<kRingFmax, kRingLine, kRingBlock, kRingProd>::kBytes;
-  auto kernel = k_part_scatter_ring<SRC, CLAIM, kRingFmax, kRingLine, kRingBlock, kRingProd, TPT>;
+  auto kernel = k_part_scatter_ring<SRC, CLAIM, kRingFmax, kRingLine, kRingBlock, kRingProd, TPT, FULL>;
   OLAP_TRY(allow_lds(ctx, reinterpret_cast<const void*>(kernel), kLds));
   char label[96];
-  std::snprintf(label, sizeof label, "olap::k_part_scatter_ring<%d, %s, %d, %d, %d, %d, %d>", SRC, CLAIM ? "true" : "false", kRingFmax, kRingLine,
-                kRingBlock, kRingProd, TPT);
+  std::snprintf(label, sizeof label, "olap::k_part_scatter_ring<%d, %s, %d, %d, %d, %d, %d, %d>", SRC, CLAIM ? "true" : "false", kRingFmax, kRingLine,
+                kRingBlock, kRingProd, TPT, FULL);
   ctx->phase_kernel[CLAIM ? PH_PART_SCATTER_CLAIM : PH_PART_SCATTER_CAP] = label;
   hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kRingBlock), kLds, ctx->stream, src, shift, fbits, out, co, cq);
   OLAP_HIP(ctx, hipGetLastError());
   return OLAP_OK;
 }
 
+// full: 0 | 1 | 2 -- column input of whole, 16-byte aligned tiles (load_tile's FULL), with / without a payload column
 static int launch_ring(olap_ctx* ctx, bool cols, bool claim, unsigned blocks, const PassSrc& src, uint32_t shift, uint32_t fbits, uint2* out,
-                       const CapOut& co, const ClaimOut& cq) {
+                       const CapOut& co, const ClaimOut& cq, int full = 0) {
   const bool t4 = ctx->ring_tpt == 4;
   if (claim) {
+    if (cols && !t4 && full == 1) return launch_ring_as<SRC_COLS, true, 8, 1>(ctx, blocks, src, shift, fbits, out, co, cq);
+    if (cols && !t4 && full == 2) return launch_ring_as<SRC_COLS, true, 8, 2>(ctx, blocks, src, shift, fbits, out, co, cq);
     if (cols) return t4 ? launch_ring_as<SRC_COLS, true, 4>(ctx, blocks, src, shift, fbits, out, co, cq)
                         : launch_ring_as<SRC_COLS, true, 8>(ctx, blocks, src, shift, fbits, out, co, cq);
     return t4 ? launch_ring_as<SRC_TUPLES, true, 4>(ctx, blocks, src, shift, fbits, out, co, cq)
@@ -404,7 +407,8 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
         PhaseScope ps(ctx, PH_PART_SCATTER_CLAIM);
         const ClaimOut co{ccap, cursor, d_overflow, weave ? kWeaveShift : 0u, (uint32_t)(n_seg * F)};
 
-        if (ring_claim) OLAP_TRY(launch_ring(ctx, cols, true, (unsigned)blocks, src, shift, fbits, out, CapOut{}, co));
+        const int full = cols && cs.full_units && cs.view.unit_rows == ring_tile(ctx) && ctx->ring_full_tiles ? (has_payload ? 1 : 2) : 0;
+        if (ring_claim) OLAP_TRY(launch_ring(ctx, cols, true, (unsigned)blocks, src, shift, fbits, out, CapOut{}, co, full));
         else OLAP_TRY(launch_claim(ctx, cols, g2, (unsigned)blocks, src, shift, fbits, out, co));
         OLAP_HIP(ctx, hipGetLastError());
       }
@@ -594,7 +598,8 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
     if (direct) {
       uint64_t dgrid = (uint64_t)ctx->compute_units * 8;
       if (dgrid > P) dgrid = P;
-      hipLaunchKernelGGL(k_join_probe_direct, dim3((unsigned)dgrid), dim3(kDBlock), 0, ctx->stream, rv, lv, P, table_bits,
+      const uint32_t run = (uint32_t)std::max(1, ctx->probe_run);
+      hipLaunchKernelGGL(k_join_probe_direct, dim3((unsigned)dgrid), dim3(kDBlock), 0, ctx->stream, rv, lv, P, run, table_bits,
                          (uint32_t)ctx->hash_skip_bits, d_fk, d_y, d_x, pair_ok, d_cnt, miss_bits);
     } else {
       hipLaunchKernelGGL(k_join_probe, dim3((unsigned)grid), dim3(kJBlock), 0, ctx->stream, rv, lv, P, d_fk, d_y, d_x,
@@ -773,6 +778,15 @@ int olap_set_tuning(olap_ctx* ctx, const char* key, int value) {
   if (!std::strcmp(key, "ring_scatter")) {
     if (value < 0 || value > 3) return ctx->fail(OLAP_ERR_INVALID, "ring_scatter must be 0 (off), 1 (claiming pass), 2 (capacity pass) or 3 (both)");
     ctx->ring_scatter = value;
+    return OLAP_OK;
+  }
+  if (!std::strcmp(key, "probe_run")) {
+    if (value < 1 || value > 65536) return ctx->fail(OLAP_ERR_INVALID, "probe_run must be in [1, 65536]");
+    ctx->probe_run = value;
+    return OLAP_OK;
+  }
+  if (!std::strcmp(key, "ring_full_tiles")) {
+    ctx->ring_full_tiles = value != 0;
     return OLAP_OK;
   }
   if (!std::strcmp(key, "claim_weave")) {

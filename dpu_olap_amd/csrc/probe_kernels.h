@@ -192,7 +192,7 @@ constexpr int kDBlock = 512;
 // key is only its identity if every tuple of the partition shares those leading bits.  That precondition is CHECKED:
 // tuples whose leading bits differ from the partition's first build tuple are counted in counters[5] and the join
 // fails with OLAP_ERR_INVALID instead of returning the x of another key.
-__global__ __launch_bounds__(kDBlock, 4) void k_join_probe_direct(PartView RV, PartView LV, uint32_t nparts,
+__global__ __launch_bounds__(kDBlock, 4) void k_join_probe_direct(PartView RV, PartView LV, uint32_t nparts, uint32_t run,
                                                                uint32_t table_bits, uint32_t skip_bits, uint32_t* out_fk,
                                                                uint32_t* out_y, uint32_t* out_x,
                                                                uint32_t pair_store_ok, unsigned long long* counters,
@@ -205,7 +205,10 @@ __global__ __launch_bounds__(kDBlock, 4) void k_join_probe_direct(PartView RV, P
   uint32_t my_miss = 0, my_dup = 0, my_foreign = 0;
   uint64_t my_max = 0;
   const uint32_t top_shift = skip_bits ? 32u - skip_bits : 0u;
-  for (uint32_t p = blockIdx.x; p < nparts; p += gridDim.x) {
+  // partitions are dealt to the workgroups in runs of `run` consecutive ones (1: round-robin)
+  const uint32_t n_runs = (nparts + run - 1) / run;
+  for (uint32_t q = blockIdx.x * run; q < n_runs * run; q += gridDim.x * run)
+  for (uint32_t p = q; p < min(q + run, nparts); ++p) {
     const uint64_t rlo = RV.cap ? (uint64_t)p * RV.cap : RV.off[p];
     const uint64_t rhi = RV.cap ? rlo + RV.cnt[p] : RV.off[p + 1];
     const uint64_t llo = LV.cap ? (uint64_t)p * LV.cap : LV.off[p];

@@ -55,16 +55,50 @@ struct RingCfg {
   static_assert(FMAX <= kProd, "the producers serve the claims, one bucket per thread");
 };
 
-template <int TPT>
+// A tile's tuples in the producers' registers.  FULL = 0: scalar arrays filled by load_tile (any source, ragged tiles,
+// unaligned buffers).  FULL = 1 / 2: column input of whole aligned tiles with / without a payload column -- the 16-byte
+// vectors as loaded (load_tile_full), read component by component.
+template <int TPT, int SRC, int FULL>
 struct TileRegs {
-  uint32_t key[TPT], pay[TPT], bk[TPT];
+  uint32_t k[TPT], p[TPT], bk[TPT];
   uint32_t mask;
+  __device__ __forceinline__ uint32_t key(int i) const { return k[i]; }
+  __device__ __forceinline__ uint32_t pay(int i) const { return p[i]; }
+  template <int BLOCK, int TILE, bool NT>
+  __device__ __forceinline__ void load(const PassSrc& s, const TileRange& r, uint64_t tile, ColsCursor& cur) {
+    mask = load_tile<SRC, BLOCK, true, TILE, NT>(s, r, tile, cur, k, p);
+  }
+  __device__ __forceinline__ void pin() {  // a scheduling barrier for the tile's loads (see step())
+#pragma unroll
+    for (int i = 0; i < TPT; ++i) asm volatile("" : "+v"(k[i]) : : "memory");
+  }
 };
+template <int TPT, bool HASPAY>
+struct TileRegsFull {
+  static_assert(TPT == 8, "two key and two payload vectors per thread");
+  u32x4_t k0, k1, p0, p1;  // (named members, not arrays: arrays of vectors read by element stayed in scratch memory)
+  uint32_t bk[TPT];
+  uint32_t mask;
+  __device__ __forceinline__ uint32_t key(int i) const { return i < 4 ? k0[i & 3] : k1[i & 3]; }
+  __device__ __forceinline__ uint32_t pay(int i) const { return i < 4 ? p0[i & 3] : p1[i & 3]; }
+  template <int BLOCK, int TILE, bool NT>
+  __device__ __forceinline__ void load(const PassSrc& s, const TileRange&, uint64_t tile, ColsCursor& cur) {
+    load_tile_full<BLOCK, TILE, HASPAY, NT>(s, tile, cur, k0, k1, p0, p1);
+    mask = (1u << TPT) - 1u;
+  }
+  __device__ __forceinline__ void pin() {
+    asm volatile("" : "+v"(k0), "+v"(k1) : : "memory");
+  }
+};
+template <int TPT>
+struct TileRegs<TPT, SRC_COLS, 1> : TileRegsFull<TPT, true> {};
+template <int TPT>
+struct TileRegs<TPT, SRC_COLS, 2> : TileRegsFull<TPT, false> {};
 
 // SRC: SRC_COLS (pass 0 from the Arrow columns) or SRC_TUPLES.  CLAIM: claimed allotments + fillers
 // (any number of workgroups per output bucket; ClaimOut) instead of the capacity layout (one
 // workgroup per input segment; CapOut).  Tiles of NPROD * 64 * TPT tuples.
-template <int SRC, bool CLAIM, int FMAX, int LINE, int BLOCK, int NPROD, int TPT>
+template <int SRC, bool CLAIM, int FMAX, int LINE, int BLOCK, int NPROD, int TPT, int FULL = 0>
 __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring(PassSrc s, uint32_t shift, uint32_t fbits, uint2* out, CapOut co,
                                                                ClaimOut cq) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -118,28 +152,29 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring(PassSrc s, uint32_t
     // ------------------------------------------------------------ producers
     const uint32_t expect = r.seg & s.chk_mask;
     const uint32_t dummy = FMAX + (lane & (C::kDummy - 1));  // bucket id of an invalid tuple: counter cl[dummy], slot ring[FMAX * kRingMin + ...]
-    auto hash_tile = [&](TileRegs<TPT>& t) {
+    using Regs = TileRegs<TPT, SRC, FULL>;
+    auto hash_tile = [&](Regs& t) {
 #pragma unroll
       for (int i = 0; i < TPT; ++i) {
-        const uint32_t h = wang_hash(t.key[i]);
+        const uint32_t h = wang_hash(t.key(i));
         // fillers of a claiming producer pass carry another bucket's hash bits (chk_mask 0: none)
         const bool ok = (((t.mask >> i) & 1u) != 0) & (((h >> s.chk_shift) & s.chk_mask) == expect);
         t.bk[i] = ok ? ((h >> shift) & (F - 1u)) : dummy;
       }
     };
     ColsCursor cur;
-    TileRegs<TPT> A, B, Cc;
+    Regs A, B, Cc;
     A.mask = B.mask = Cc.mask = 0;
 #pragma unroll
     for (int i = 0; i < TPT; ++i) A.bk[i] = B.bk[i] = Cc.bk[i] = dummy;
-    if (tile_ok(r.t0)) A.mask = load_tile<SRC, kProd, true, TILE, OLAP_RING_NT_LOAD != 0>(s, r, tile_at(r.t0), cur, A.key, A.pay);
-    if (tile_ok(r.t0 + 1)) B.mask = load_tile<SRC, kProd, true, TILE, OLAP_RING_NT_LOAD != 0>(s, r, tile_at(r.t0 + 1), cur, B.key, B.pay);
+    if (tile_ok(r.t0)) A.template load<kProd, TILE, OLAP_RING_NT_LOAD != 0>(s, r, tile_at(r.t0), cur);
+    if (tile_ok(r.t0 + 1)) B.template load<kProd, TILE, OLAP_RING_NT_LOAD != 0>(s, r, tile_at(r.t0 + 1), cur);
     hash_tile(A);
     // CLAIM: thread t refills the reserve of bucket t
     const uint32_t tb = threadIdx.x;
     uint32_t claimed = 0;   // the atomic's answer, in flight until the next tile's loads have been awaited
     bool pending = false;
-    auto step = [&](uint64_t tile, TileRegs<TPT>& c, TileRegs<TPT>& nx, TileRegs<TPT>& n2) {
+    auto step = [&](uint64_t tile, Regs& c, Regs& nx, Regs& n2) {
       // insert tile `tile`: one returning LDS atomic + one LDS store per tuple
       uint32_t v[TPT];
 #pragma unroll
@@ -151,7 +186,7 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring(PassSrc s, uint32_t
         const bool valid = c.bk[i] < (uint32_t)FMAX;
         const bool fits = sl < kRing;
         const uint32_t at = (valid & fits) ? c.bk[i] * kRing + ((hd + sl) & (kRing - 1)) : FMAX * C::kRingMin + (lane & (C::kDummy - 1));
-        ring[at] = make_uint2(c.key[i], c.pay[i]);
+        ring[at] = make_uint2(c.key(i), c.pay(i));
         dmask |= (valid & !fits) ? 1u << i : 0u;  // the ring is full: this tuple is placed after the flush
       }
       if (dmask) misc[0] = (uint32_t)tile + 1u;
@@ -159,8 +194,7 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring(PassSrc s, uint32_t
       // Pin the schedule: tile + 1 is awaited and hashed HERE, beside the flush (the compiler otherwise moves
       // the hashing in front of barrier 1 or down to the next insert), and tile + 2 is requested only after
       // tile + 1 has arrived, so that the wait for tile + 1 (vmcnt(0)) never waits for loads issued a moment ago.
-#pragma unroll
-      for (int i = 0; i < TPT; ++i) asm volatile("" : "+v"(nx.key[i]) : : "memory");
+      nx.pin();
       hash_tile(nx);
 #pragma unroll
       for (int i = 0; i < TPT; ++i) asm volatile("" : "+v"(nx.bk[i]) : : "memory");
@@ -177,7 +211,7 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring(PassSrc s, uint32_t
         }
       }
       n2.mask = 0;
-      if (tile_ok(tile + 2)) n2.mask = load_tile<SRC, kProd, true, TILE, OLAP_RING_NT_LOAD != 0>(s, r, tile_at(tile + 2), cur, n2.key, n2.pay);
+      if (tile_ok(tile + 2)) n2.template load<kProd, TILE, OLAP_RING_NT_LOAD != 0>(s, r, tile_at(tile + 2), cur);
       __syncthreads();  // ---- barrier 2: complete lines are out, the rings have room again
       if (misc[0] == (uint32_t)tile + 1u) {  // some bucket was hot in this tile (uniform)
 #pragma unroll
@@ -187,9 +221,9 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring(PassSrc s, uint32_t
             const uint2 info = hot[b];
             const uint32_t full = info.y & 0xFFFFu, hd = info.y >> 16, sl = v[i] & 0xFFFFu;
             if (sl < full) {  // goes straight to the range the owner reserved (dropped when the region is full)
-              if (info.x != kRingNone) gstore2(out + at((uint64_t)r.seg * F + b, info.x + (sl - kRing)), make_uint2(c.key[i], c.pay[i]));
+              if (info.x != kRingNone) gstore2(out + at((uint64_t)r.seg * F + b, info.x + (sl - kRing)), make_uint2(c.key(i), c.pay(i)));
             } else {          // tail of the tile: the bucket's new residue
-              ring[b * kRing + ((hd + (sl - full)) & (kRing - 1))] = make_uint2(c.key[i], c.pay[i]);
+              ring[b * kRing + ((hd + (sl - full)) & (kRing - 1))] = make_uint2(c.key(i), c.pay(i));
             }
           }
         }

@@ -1129,9 +1129,32 @@ def test_join_ring_scatter_vs_digest(dev, shape, tpt):
     assert timers.get("partition-scatter-claim", 0) and timers.get("partition-scatter-capacity", 0), timers
     assert dev.get_counter("join_attempts") == 1 and dev.get_counter("join_region_overflows") == 0   # no exact rerun behind the result
     assert not timers.get("partition-hist", 0), timers
+    # whole aligned 4096-row tiles are read by the straight-line loader (last template argument 1), anything else by the generic one
+    claim_kernel = dev.phase_kernel("partition-scatter-claim")
+    assert claim_kernel.endswith(", 1>" if (tpt == 8 and shape != "ragged") else ", 0>"), claim_kernel
     ofk = dev.to_host(out["fk"])
     part = oracle.wang_hash_np(ofk) >> np.uint32(16)
     assert (np.diff(part.astype(np.int64)) >= 0).all()
+    if shape == "uniform" and tpt == 8:
+        # selection vectors (no payload columns: payload = row index, loader variant 2), and the generic loader on the same input
+        for knob, suffix in ((1, ", 2>"), (0, ", 0>")):
+            dev.join_configure(16, 8)
+            dev.set_tuning("claim_mode", 2)
+            dev.set_tuning("ring_full_tiles", knob)
+            try:
+                js = o.JoinGpu(dev, [batch("fk", b) for b in range(nb)], [batch("pk", b) for b in range(nb)], select=True).Prepare()
+                sel = js.Run()
+            finally:
+                dev.join_configure(-1, 0)
+                dev.set_tuning("claim_mode", 1)
+                dev.set_tuning("ring_full_tiles", 1)
+            assert dev.phase_kernel("partition-scatter-claim").endswith(suffix)
+            sfk, sy, sx = dev.to_host(sel["fk"]), dev.to_host(sel["y"]), dev.to_host(sel["x"])
+            np.testing.assert_array_equal(fk[sy], sfk)
+            np.testing.assert_array_equal(pk[sx], sfk)
+            assert np.array_equal(np.sort(sy), np.arange(n, dtype=np.uint32))
+            for c in sel.values():
+                dev.release(o.DeviceArray(c.ptr, 0))
     for c in list(d.values()) + list(out.values()):
         dev.release(o.DeviceArray(c.ptr, 0))
 
