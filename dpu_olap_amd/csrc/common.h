@@ -94,7 +94,7 @@ struct olap_ctx {
   int probe_run = 1;       // direct-table probe: consecutive partitions per workgroup turn
   int ring_full_tiles = 1; // ring scatter from columns: the straight-line loader when all batches are whole aligned tiles
   int claim_weave = 1;     // claiming ring scatter writes woven regions (radix_kernels.h woven_at)
-  int ring_interleave = 0; // ring scatter from columns: tiles dealt to the workgroups round-robin in chunks of this many (0: one contiguous run each)
+  int ring_interleave = -1; // ring scatter from columns: tiles dealt to the workgroups round-robin in chunks of this many (0: one contiguous run each; -1: automatic)
   int ring_tpt = 8;        // tuples per producer thread and tile of the ring scatter (8: 4096-tuple tiles, 4: 2048)
   int claim_mode = 1;      // pass 0 of a two-pass plan without histogram (claimed allotments): 0 off, 1 auto, 2 always
   int hash_skip_bits = 0;  // top hash bits already fixed by an upstream owner split

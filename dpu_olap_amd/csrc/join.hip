@@ -375,7 +375,11 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
       if (nb == 0) nb = 1;
       src.tiles_per_block = (tiles + nb - 1) / nb;
       if (src.tiles_per_block == 0) src.tiles_per_block = 1;
-      src.interleave = ring_claim ? (uint32_t)ctx->ring_interleave : 0u;
+      // -1 (default): tile by tile with the straight-line loader (as a plain copy is fastest with round-robin tiles:
+      // profiles/r2_ubench_copy_rate.txt), one contiguous run per workgroup with the generic loader (which pays a batch
+      // lookup whenever its tiles are not consecutive)
+      const bool full_loader = cs.full_units && cs.view.unit_rows == ring_tile(ctx) && ctx->ring_full_tiles && ctx->ring_tpt != 4;
+      src.interleave = !ring_claim ? 0u : ctx->ring_interleave >= 0 ? (uint32_t)ctx->ring_interleave : full_loader ? 1u : 0u;
       blocks = (tiles + src.tiles_per_block - 1) / src.tiles_per_block;
       if (blocks == 0) blocks = 1;
       bseg = blocks;
@@ -794,7 +798,7 @@ int olap_set_tuning(olap_ctx* ctx, const char* key, int value) {
     return OLAP_OK;
   }
   if (!std::strcmp(key, "ring_interleave")) {
-    if (value < 0 || value > 4096) return ctx->fail(OLAP_ERR_INVALID, "ring_interleave must be in [0, 4096]");
+    if (value < -1 || value > 4096) return ctx->fail(OLAP_ERR_INVALID, "ring_interleave must be in [-1, 4096]");
     ctx->ring_interleave = value;
     return OLAP_OK;
   }

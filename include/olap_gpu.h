@@ -289,6 +289,8 @@ int olap_join_configure(olap_ctx* ctx, int radix_bits_total, int max_bits_per_pa
  *   ring_tpt           8 (default) | 4 tuples per producer thread and tile of the ring scatter
  *   ring_full_tiles    1 column input whose batches are all whole 4096-row tiles in 16-byte aligned buffers is read by a
  *                      loader without the ragged fallback (keeps the prefetch asynchronous; default) | 0 generic loader
+ *   ring_interleave    -1 automatic (default: pass 0's column tiles are dealt to the workgroups round-robin with the
+ *                      whole-tile loader, as contiguous runs otherwise) | 0 contiguous runs | N round-robin in chunks of N tiles
  *   claim_weave        1 the claiming ring scatter weaves its regions in 64 KiB chunks, so that the lines the chip writes at
  *                      any moment lie within ~32 MiB (address-translation locality; default) | 0 regions one after the other
  *   direct_table       1 direct-address LDS table when <= 14 hash bits remain (default) | 0 probing table
