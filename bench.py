@@ -256,6 +256,10 @@ def main():
     if cold_first_step_ms is None and args.steps == 1:
         cold_first_step_ms = dt * 1e3          # no warm-up: the one timed step was the cold one
     timers = ctx.timers()
+    if os.environ.get("OLAP_BENCH_DEBUG_ADDR") == "1":   # placement study: where the buffers of this process lie
+        print(json.dumps({"addr": {"fk": hex(fk.data_ptr()), "y": hex(y.data_ptr()), "pk": hex(pk.data_ptr()), "x": hex(x.data_ptr()),
+                                   "out": [hex(t.data_ptr()) for t in result[:3]], "arena_base": hex(ctx.get_counter("arena_base")),
+                                   "arena_bytes": ctx.get_counter("arena_bytes")}}), file=sys.stderr, flush=True)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -829,6 +829,8 @@ int olap_get_counter(olap_ctx* ctx, const char* name, uint64_t* out_value) {
   if (!ctx || !name || !out_value) return OLAP_ERR_INVALID;
   if (!std::strcmp(name, "join_attempts")) *out_value = ctx->last_join_attempts;
   else if (!std::strcmp(name, "join_region_overflows")) *out_value = ctx->last_join_region_overflows;
+  else if (!std::strcmp(name, "arena_base")) *out_value = (uint64_t)(uintptr_t)ctx->ws;
+  else if (!std::strcmp(name, "arena_bytes")) *out_value = ctx->ws_bytes;
   else return ctx->fail(OLAP_ERR_INVALID, "unknown counter '%s'", name);
   return OLAP_OK;
 }

@@ -355,22 +355,34 @@ BENCHMARK_REGISTER_F(PartitionFixture, BM_PartitionGpu)
 // range); the operators are driven through the C ABI on device pointers.
 class ResidentColumns {
  public:
+  // The columns are carved out of ONE allocation with a skew of (2c + 1) MiB + c * 4352 B: equal-sized columns from
+  // separate allocations lie an exact power of two apart and alias on the HBM channels when a kernel streams them in
+  // lockstep (the join's probe: 20.7 vs 23.7 ms at SF=2048).
   ResidentColumns(olap::Device& dev, int64_t batches, int64_t batch_rows, int columns) : dev_(dev), rows_(batches * batch_rows) {
+    const uint64_t bytes = ((uint64_t)std::max<int64_t>(rows_, 1) * 4 + 255) & ~255ull;
+    std::vector<uint64_t> offset((size_t)columns);
+    uint64_t total = 0;
     for (int c = 0; c < columns; ++c) {
-      void* p = nullptr;
-      if (olap_malloc(dev_.ctx(), (uint64_t)std::max<int64_t>(rows_, 1) * 4, &p) != OLAP_OK) {
-        ok_ = false;
-        break;
-      }
+      total += ((2ull * c + 1) << 20) + (uint64_t)c * 4352;
+      total = (total + 255) & ~255ull;
+      offset[(size_t)c] = total;
+      total += bytes;
+    }
+    if (olap_malloc(dev_.ctx(), total, &base_) != OLAP_OK) {
+      ok_ = false;
+      base_ = nullptr;
+    }
+    for (int c = 0; c < columns && ok_; ++c) {
+      char* p = static_cast<char*>(base_) + offset[(size_t)c];
       cols_.push_back(p);
       std::vector<const void*> ptrs;
-      for (int64_t b = 0; b < batches; ++b) ptrs.push_back(static_cast<const char*>(p) + (uint64_t)b * batch_rows * 4);
+      for (int64_t b = 0; b < batches; ++b) ptrs.push_back(p + (uint64_t)b * batch_rows * 4);
       tables_.push_back(std::move(ptrs));
     }
     lens_.assign((size_t)batches, (uint64_t)batch_rows);
   }
   ~ResidentColumns() {
-    for (void* p : cols_) (void)olap_free(dev_.ctx(), p);
+    if (base_) (void)olap_free(dev_.ctx(), base_);
   }
   bool ok() const { return ok_; }
   void* column(int c) const { return cols_[c]; }
@@ -384,6 +396,7 @@ class ResidentColumns {
   olap::Device& dev_;
   int64_t rows_;
   bool ok_ = true;
+  void* base_ = nullptr;
   std::vector<void*> cols_;
   std::vector<std::vector<const void*>> tables_;
   std::vector<uint64_t> lens_;

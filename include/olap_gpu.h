@@ -303,7 +303,8 @@ int olap_set_tuning(olap_ctx* ctx, const char* key, int value);
  * histogram round trip, host/join/join_dpu.cc:54-66).  Names:
  *   "join_attempts"          1 = the first plan went through; > 1 = it was redone (exact partitioning after a region
  *                            overflow, or more radix bits after an LDS-table overflow)
- *   "join_region_overflows"  (workgroup, bucket) regions of the histogram-free passes that overflowed in the first attempt */
+ *   "join_region_overflows"  (workgroup, bucket) regions of the histogram-free passes that overflowed in the first attempt
+ *   "arena_base", "arena_bytes"  device address and size of the context's scratch arena (placement studies) */
 int olap_get_counter(olap_ctx* ctx, const char* name, uint64_t* out_value);
 /* Multi-GPU: when the inputs of this context were already split by the top
  * `bits` bits of wang_hash(key) (olap_partition_u32 with nr_partitions = #GPUs,

@@ -6,5 +6,6 @@ for i in $(seq $N); do
   echo "--- run $i  $(date +%T)"
   rocm-smi --showclocks --showpower --showtemp 2>/dev/null | grep -E "sclk|mclk|fclk|Power|Temperature \(Sensor (junction|memory|edge)" | sed 's/^GPU\[0\]\s*: //' | tr '\n' ';'
   echo
-  timeout -k 10 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['phase_ms_per_step'])" || echo FAILED
+  OLAP_BENCH_DEBUG_ADDR=1 timeout -k 10 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>gpurun_out/.addr.$i | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['phase_ms_per_step'])" || echo FAILED
+  grep '"addr"' gpurun_out/.addr.$i
 done
