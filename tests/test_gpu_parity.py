@@ -1159,6 +1159,47 @@ def test_join_ring_scatter_vs_digest(dev, shape, tpt):
         dev.release(o.DeviceArray(c.ptr, 0))
 
 
+@pytest.mark.parametrize("ring,weave", [(1, 1), (1, 0), (2, 1), (3, 0)])
+def test_join_ring_scatter_mixed_with_write_combining_kernels(dev, ring, weave):
+    """ring_scatter = 1: the claiming ring scatter (woven or plain regions) feeds the write-combining capacity-layout kernel;
+    2: the write-combining claiming kernel feeds the ring scatter; 3 with claim_weave = 0: both ring passes on plain
+    regions.  Same digest in every combination."""
+    o = _ops()
+    from dpu_olap_amd import datagen as dg
+    rows, nb = 1 << 20, 32
+    n = rows * nb
+    cols = {k: dev.empty(n, "uint32") for k in ("fk", "y", "pk", "x", "exp")}
+    dev.gen_fk_u32(cols["fk"].ptr, n, dg.SEED, dg.STREAM_FK, 0, rows, rows)
+    dev.gen_uniform_u32(cols["y"].ptr, n, dg.SEED, dg.STREAM_Y, 0)
+    dev.gen_index_u32(cols["pk"].ptr, n, 0)
+    dev.gen_uniform_u32(cols["x"].ptr, n, dg.SEED, dg.STREAM_X, 0)
+    dev.gen_uniform_u32_at(cols["exp"].ptr, cols["fk"].ptr, n, dg.SEED, dg.STREAM_X)
+    expect = dev.checksum_rows3_u32(cols["fk"].ptr, cols["y"].ptr, cols["exp"].ptr, n)
+    batch = lambda c, b: o.DeviceArray(cols[c].ptr + 4 * b * rows, rows, "uint32")
+    dev.join_configure(16, 8)
+    dev.set_tuning("claim_mode", 2)
+    dev.set_tuning("ring_scatter", ring)
+    dev.set_tuning("claim_weave", weave)
+    try:
+        j = o.JoinGpu(dev, [(batch("fk", b), batch("y", b)) for b in range(nb)],
+                      [(batch("pk", b), batch("x", b)) for b in range(nb)]).Prepare()
+        out = j.Run()
+        timers = j.Timers()
+    finally:
+        dev.join_configure(-1, 0)
+        dev.set_tuning("claim_mode", 1)
+        dev.set_tuning("ring_scatter", 3)
+        dev.set_tuning("claim_weave", 1)
+    assert out["fk"].rows == n and j.stats["missing_keys"] == 0, j.stats
+    assert dev.checksum_rows3_u32(out["fk"].ptr, out["y"].ptr, out["x"].ptr, n) == expect
+    assert timers.get("partition-scatter-claim", 0) and timers.get("partition-scatter-capacity", 0) and not timers.get("partition-hist", 0), timers
+    assert dev.get_counter("join_attempts") == 1
+    claim_k, cap_k = dev.phase_kernel("partition-scatter-claim"), dev.phase_kernel("partition-scatter-capacity")
+    assert ("k_part_scatter_ring" in claim_k) == bool(ring & 1) and ("k_part_scatter_ring" in cap_k) == bool(ring & 2), (claim_k, cap_k)
+    for c in list(cols.values()) + list(out.values()):
+        dev.release(o.DeviceArray(c.ptr, 0))
+
+
 def test_join_ring_scatter_skew_falls_back_to_exact(dev):
     """Ring scatter with a skewed probe side (1024 distinct foreign keys): the claimed regions / capacity
     regions overflow, the kernels drop what does not fit and raise the overflow counter, and the join is
