@@ -508,6 +508,7 @@ struct JoinIn {
   const uint2* r_tuples = nullptr;
   const Presplit* l_pre = nullptr;  // both or neither; same n_seg
   const Presplit* r_pre = nullptr;
+  bool broadcast = false;           // the right table fits one LDS table: no partitioning (k_join_broadcast)
 };
 
 static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t* out_y, uint32_t* out_x, int out_mem,
@@ -523,8 +524,13 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
   const int in_mem = in.in_mem;
   PassPlan plan;
   const uint32_t pre_bits = in.l_pre ? in.l_pre->bits : 0u;  // already fixed by the pre-split
+  const bool bc = in.broadcast;
   if (total_bits <= pre_bits) total_bits = pre_bits + 1;
-  OLAP_TRY(make_plan(ctx, total_bits - pre_bits, &plan));
+  if (bc) {
+    plan = PassPlan{};  // no radix pass at all
+  } else {
+    OLAP_TRY(make_plan(ctx, total_bits - pre_bits, &plan));
+  }
   if (pre_bits + plan.total_bits + (uint32_t)ctx->hash_skip_bits > 32)
     return ctx->fail(OLAP_ERR_INVALID, "radix bits (%u) + skipped hash bits (%d) exceed 32", pre_bits + plan.total_bits,
                      ctx->hash_skip_bits);
@@ -538,8 +544,8 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
   const uint64_t maxN = NL > NR ? NL : NR;
   const bool lcap = allow_capacity && capacity_eligible(ctx, NL, plan, pre_bits);
   const bool rcap = allow_capacity && capacity_eligible(ctx, NR, plan, pre_bits);
-  const uint64_t lt_tuples = lcap ? (uint64_t)P * region_cap(NL, P) : NL;
-  const uint64_t rt_tuples = rcap ? (uint64_t)P * region_cap(NR, P) : NR;
+  const uint64_t lt_tuples = bc ? 0 : lcap ? (uint64_t)P * region_cap(NL, P) : NL;
+  const uint64_t rt_tuples = bc ? 0 : rcap ? (uint64_t)P * region_cap(NR, P) : NR;
   const bool lclaim = !in.l_pre && claim_eligible(ctx, NL, plan, lcap);
   const bool rclaim = !in.r_pre && claim_eligible(ctx, NR, plan, rcap);
   uint64_t tmp_tuples = maxN;  // pass-0 output: dense, or the claiming scatter's padded regions
@@ -560,8 +566,8 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
   OLAP_TRY(pinned_begin(ctx, pin));
   OLAP_TRY(ws_begin(ctx, need));
   ColumnSet lcs, rcs;
-  if (!in.l_tuples) OLAP_TRY(build_column_set(ctx, lcols, l_pay ? 2 : 1, eb, lrows, lnb, in_mem, pass0_tile(ctx, plan, lclaim), &lcs));
-  if (!in.r_tuples) OLAP_TRY(build_column_set(ctx, rcols, r_pay ? 2 : 1, eb, rrows, rnb, in_mem, pass0_tile(ctx, plan, rclaim), &rcs));
+  if (!in.l_tuples) OLAP_TRY(build_column_set(ctx, lcols, l_pay ? 2 : 1, eb, lrows, lnb, in_mem, bc ? (uint32_t)kBcTile : pass0_tile(ctx, plan, lclaim), &lcs));
+  if (!in.r_tuples) OLAP_TRY(build_column_set(ctx, rcols, r_pay ? 2 : 1, eb, rrows, rnb, in_mem, bc ? (uint32_t)kBcTile : pass0_tile(ctx, plan, rclaim), &rcs));
   uint2* tmp0 = plan.passes >= 2 ? (uint2*)ws_alloc(ctx, (tmp_tuples + 2) * 8) : nullptr;
   uint2* tmp1 = plan.passes >= 3 ? (uint2*)ws_alloc(ctx, (maxN + 2) * 8) : nullptr;
   uint2* Lt = (uint2*)ws_alloc(ctx, (lt_tuples + 2) * 8);
@@ -583,6 +589,25 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
     OLAP_HIP(ctx, hipMemsetAsync(miss_bits, 0, miss_words * 4, ctx->stream));
   }
   SideOut lso, rso;
+  if (bc) {
+    if (right_ready) OLAP_HIP(ctx, hipStreamWaitEvent(ctx->stream, right_ready, 0));
+    PassSrc ls{}, rs{};
+    ls.v = lcs.view;
+    ls.key_ptrs = lcs.dev_ptr_tables[0];
+    ls.pay_ptrs = l_pay ? lcs.dev_ptr_tables[1] : nullptr;
+    rs.v = rcs.view;
+    rs.key_ptrs = rcs.dev_ptr_tables[0];
+    rs.pay_ptrs = r_pay ? rcs.dev_ptr_tables[1] : nullptr;
+    const uint64_t tiles = lcs.view.total_units;
+    uint64_t nb = std::min<uint64_t>((uint64_t)ctx->compute_units * 8, std::max<uint64_t>(tiles, 1));
+    ls.tiles_per_block = (tiles + nb - 1) / nb;
+    if (ls.tiles_per_block == 0) ls.tiles_per_block = 1;
+    const uint64_t blocks = std::max<uint64_t>(1, (tiles + ls.tiles_per_block - 1) / ls.tiles_per_block);
+    PhaseScope ps(ctx, PH_JOIN_PROBE);
+    ctx->phase_kernel[PH_JOIN_PROBE] = "olap::k_join_broadcast";
+    hipLaunchKernelGGL(k_join_broadcast, dim3((unsigned)blocks), dim3(kJBlock), 0, ctx->stream, rs, ls, d_fk, d_y, d_x, d_cnt, miss_bits);
+    OLAP_HIP(ctx, hipGetLastError());
+  } else {
   OLAP_TRY(partition_side(ctx, lcs, l_pay, in.l_tuples, NL, plan, (uint32_t)ctx->hash_skip_bits, tmp0, tmp1, Lt, lcap,
                           d_cnt + 4, &lso, in.l_pre, lclaim));
   if (right_ready) {  // the right table may still be arriving (olap_join_set_right_ready_event)
@@ -590,7 +615,8 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
   }
   OLAP_TRY(partition_side(ctx, rcs, r_pay, in.r_tuples, NR, plan, (uint32_t)ctx->hash_skip_bits, tmp0, tmp1, Rt, rcap,
                           d_cnt + 4, &rso, in.r_pre, rclaim));
-  {
+  }
+  if (!bc) {
     PhaseScope ps(ctx, PH_JOIN_PROBE);
     uint64_t grid = (uint64_t)ctx->compute_units * 8;
     if (grid > P) grid = P;
@@ -718,7 +744,15 @@ static int join_run(olap_ctx* ctx, const JoinIn& jin, uint64_t NL, uint64_t NR, 
     // (one bit MORE than the probing table would need is still the better plan: the same two passes, and a probe that is
     // twice as fast per row -- SF=256: 15.5 -> 10.x ms per join)
     if (ctx->direct_table && dbits >= 1 && dbits <= (int)bits + 1 && (NR >> dbits) >= 2048) bits = (uint32_t)dbits;
+    // A small build side must not leave the probe to a handful of workgroups (one partition = one workgroup at a time;
+    // 2^28 x 2^16 rows took 52 ms with the 16 partitions the table size asks for): at least 1024 partitions -- still
+    // one pass -- when the probe side is large.
+    if (bits < 10 && NL >= (1ull << 22)) bits = 10;
   }
+  // ... and a build side that fits ONE LDS table is not partitioned at all (k_join_broadcast)
+  JoinIn jb = jin;
+  jb.broadcast = ctx->broadcast_join && ctx->radix_bits_total < 0 && !jin.l_tuples && !jin.r_tuples && !jin.l_pre &&
+                 ctx->hash_skip_bits == 0 && NR <= (uint64_t)kTableCap;
   if (jin.l_pre && bits <= jin.l_pre->bits) bits = jin.l_pre->bits + 1;  // at least one pass gathers the chunks
   unsigned long long counters[6] = {0, 0, 0, 0, 0};
   uint64_t kept_rows = NL;
@@ -727,7 +761,7 @@ static int join_run(olap_ctx* ctx, const JoinIn& jin, uint64_t NL, uint64_t NR, 
   ctx->last_join_region_overflows = 0;
   for (int attempt = 0; attempt < 4; ++attempt) {
     ++ctx->last_join_attempts;
-    OLAP_TRY(join_once(ctx, jin, out_fk, out_y, out_x, out_mem, NL, NR, bits, allow_capacity, stats, counters, &kept_rows,
+    OLAP_TRY(join_once(ctx, jb, out_fk, out_y, out_x, out_mem, NL, NR, bits, allow_capacity, stats, counters, &kept_rows,
                        attempt == 0 ? right_ready : nullptr));
     if (attempt == 0) ctx->last_join_region_overflows = counters[4];
     if (counters[4]) {  // a fixed-capacity region overflowed (skew): redo with exact partitioning
@@ -784,6 +818,10 @@ int olap_set_tuning(olap_ctx* ctx, const char* key, int value) {
   if (!std::strcmp(key, "ring_scatter")) {
     if (value < 0 || value > 3) return ctx->fail(OLAP_ERR_INVALID, "ring_scatter must be 0 (off), 1 (claiming pass), 2 (capacity pass) or 3 (both)");
     ctx->ring_scatter = value;
+    return OLAP_OK;
+  }
+  if (!std::strcmp(key, "broadcast_join")) {
+    ctx->broadcast_join = value != 0;
     return OLAP_OK;
   }
   if (!std::strcmp(key, "probe_run")) {

@@ -238,6 +238,8 @@ extern "C" int olap_join_u64(olap_ctx* ctx, const uint64_t* const* left_fk_ptrs,
   }
   uint32_t bits = ctx->radix_bits_total >= 0 ? (uint32_t)std::max(1, ctx->radix_bits_total)
                                              : (uint32_t)std::max(1, ceil_log2_u64((NR + k64TargetBuildRows - 1) / k64TargetBuildRows));
+  // a small build side must not leave the probe to a handful of workgroups (as in olap_join_u32): >= 512 partitions, one pass
+  if (ctx->radix_bits_total < 0 && bits < (uint32_t)k64MaxFBits && NL >= (1ull << 22)) bits = k64MaxFBits;
   unsigned long long counters[4] = {0, 0, 0, 0};
   uint64_t kept_rows = NL;
   for (int attempt = 0; attempt < 4; ++attempt) {

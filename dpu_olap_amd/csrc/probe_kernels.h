@@ -171,6 +171,120 @@ __global__ __launch_bounds__(kJBlock, 4) void k_join_probe(PartView RV, PartView
   if (threadIdx.x == 0) atomicMax(&counters[3], (unsigned long long)my_max);
 }
 
+// ------------------------------------------------------- small build side: no partitioning
+// A right table of <= kTableCap rows fits ONE LDS table: every workgroup builds the whole table from the right
+// COLUMNS and streams its share of the LEFT COLUMNS through it -- no radix pass, no tuple buffers, and the result
+// keeps the left row order.  20 B per left row (8 read + 12 written) instead of 60 through one radix pass; and
+// the chip stays busy, where 2^1 partitions of a one-bit plan would leave the whole probe side to two workgroups
+// (2^28 x 2^12 rows: 197 ms partitioned by one bit).  The reference always partitions
+// (host/join/join_dpu.cc:82-142); Arrow's hash join -- the Native path -- has this shape.  Table semantics as
+// k_join_probe (hashtable.c:89-192: slot = low hash bits, linear probing, an equal key overwrites).
+constexpr int kBcTile = kJBlock * 8;  // rows per tile of the column views (8 per thread)
+
+__global__ __launch_bounds__(kJBlock, 4) void k_join_broadcast(PassSrc rs, PassSrc ls, uint32_t* out_fk, uint32_t* out_y,
+                                                               uint32_t* out_x, unsigned long long* counters,
+                                                               uint32_t* miss_bits) {
+  constexpr int TPT = kBcTile / kJBlock;
+  __shared__ uint32_t s_keys[kSlots];
+  __shared__ uint32_t s_vals[kSlots];
+  __shared__ uint32_t s_sp[2];  // the one key equal to the empty marker: {present, value}
+  uint32_t my_miss = 0, my_dup = 0;
+  for (uint32_t i = threadIdx.x; i < kSlots; i += kJBlock) s_keys[i] = kEmpty;
+  if (threadIdx.x == 0) s_sp[0] = 0;
+  __syncthreads();
+  {  // build: the whole right table (every workgroup; the host has checked rows <= kTableCap)
+    ColsCursor cur;
+    const TileRange none{};
+    for (uint64_t tile = 0; tile < rs.v.total_units; ++tile) {
+      uint32_t key[TPT], pay[TPT];
+      const uint32_t mask = load_tile<SRC_COLS, kJBlock, true, kBcTile>(rs, none, tile, cur, key, pay);
+#pragma unroll
+      for (int i = 0; i < TPT; ++i) {
+        if (!(mask & (1u << i))) continue;
+        const uint32_t k = key[i];
+        if (k == kEmpty) {
+          s_sp[1] = pay[i];
+          if (atomicExch(&s_sp[0], 1u)) ++my_dup;
+          continue;
+        }
+        uint32_t slot = wang_hash(k) & (kSlots - 1);
+        for (uint32_t step = 0; step < kSlots; ++step) {
+          const uint32_t old = atomicCAS(&s_keys[slot], kEmpty, k);
+          if (old == kEmpty || old == k) {  // free cell, or an equal key overwrites (hashtable.c:133)
+            s_vals[slot] = pay[i];
+            if (old == k) ++my_dup;
+            break;
+          }
+          slot = (slot + 1) & (kSlots - 1);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  {  // probe: this workgroup's run of left tiles, results at the rows' own positions
+    ColsCursor cur;
+    const TileRange r = block_tiles<SRC_COLS, kBcTile>(ls);
+    for (uint64_t tile = r.t0; tile < r.t1; ++tile) {
+      uint32_t key[TPT], pay[TPT], xs[TPT];
+      const uint32_t mask = load_tile<SRC_COLS, kJBlock, true, kBcTile>(ls, r, tile, cur, key, pay);
+      const uint64_t row0 = cur.row0 + cur.local_unit * (uint64_t)kBcTile;  // global row of the tile's first element
+#pragma unroll
+      for (int i = 0; i < TPT; ++i) {
+        xs[i] = 0;
+        if (!(mask & (1u << i))) continue;
+        const uint32_t k = key[i];
+        bool hit = false;
+        if (k == kEmpty) {
+          hit = s_sp[0] != 0;
+          xs[i] = s_sp[1];
+        } else {
+          uint32_t slot = wang_hash(k) & (kSlots - 1);
+          for (uint32_t step = 0; step < kSlots; ++step) {
+            const uint32_t kk = s_keys[slot];
+            if (kk == k) {
+              xs[i] = s_vals[slot];
+              hit = true;
+              break;
+            }
+            if (kk == kEmpty) break;
+            slot = (slot + 1) & (kSlots - 1);
+          }
+        }
+        if (!hit) {
+          ++my_miss;
+          const uint64_t row = row0 + (uint64_t)((i >> 2) * kJBlock + threadIdx.x) * 4 + (i & 3);
+          if (miss_bits) atomicOr(&miss_bits[row >> 5], 1u << (row & 31));  // drop mode: mark the row
+        }
+      }
+      const bool vec = mask == (1u << TPT) - 1u && ((((uintptr_t)(out_fk + row0)) | ((uintptr_t)(out_y + row0)) | ((uintptr_t)(out_x + row0))) & 15) == 0;
+#pragma unroll
+      for (int j = 0; j < TPT / 4; ++j) {
+        const uint64_t o = row0 + (uint64_t)(j * kJBlock + threadIdx.x) * 4;
+        if (vec) {  // (uniform: a whole tile whose rows start 16-byte aligned in all three columns)
+          gstore4(out_fk + o, make_uint4(key[4 * j], key[4 * j + 1], key[4 * j + 2], key[4 * j + 3]));
+          gstore4(out_y + o, make_uint4(pay[4 * j], pay[4 * j + 1], pay[4 * j + 2], pay[4 * j + 3]));
+          gstore4(out_x + o, make_uint4(xs[4 * j], xs[4 * j + 1], xs[4 * j + 2], xs[4 * j + 3]));
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            if (!(mask & (1u << (4 * j + k)))) continue;
+            out_fk[o + k] = key[4 * j + k];
+            out_y[o + k] = pay[4 * j + k];
+            out_x[o + k] = xs[4 * j + k];
+          }
+        }
+      }
+    }
+  }
+  const uint64_t wm = wave_reduce_add((uint64_t)my_miss);
+  const uint64_t wd = wave_reduce_add((uint64_t)(blockIdx.x == 0 ? my_dup : 0u));  // every workgroup saw the same build side
+  if (lane_id() == 0) {
+    if (wm) atomicAdd(&counters[0], (unsigned long long)wm);
+    if (wd) atomicAdd(&counters[1], (unsigned long long)wd);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(&counters[3], (unsigned long long)rs.v.total_rows);
+}
+
 // ------------------------------------------- build + probe, direct-address table
 // Every step of the Wang hash (partition.c:20-28) is invertible modulo 2^32, so DISTINCT
 // keys have DISTINCT hashes.  All keys of one final partition share the top

@@ -177,7 +177,10 @@ int olap_partition_tuples_u32(olap_ctx* ctx, const uint32_t* const* key_ptrs,
  * (hash_probe.c:9-46) with the left key and the take of the right payload.
  * left = {fk, y}, right = {pk, x}; output rows {fk, y, x} (left columns then the
  * right non-key column, join_dpu.cc:314-363), partition-major, order inside a
- * partition unspecified (tests sort, host/join/join_test.cc:27-38).
+ * partition unspecified (tests sort, host/join/join_test.cc:27-38).  A right table
+ * of <= 6144 rows (one LDS table) is joined without partitioning (stats.passes == 0,
+ * nr_partitions == 1): the rows then come in LEFT ROW ORDER.  A small right table
+ * against a large left one otherwise gets at least 1024 partitions, to keep the chip busy.
  * Contract of the reference kept: pk unique (a duplicate overwrites,
  * hashtable.c:133 -- counted in stats), every fk has a match (else
  * OLAP_ERR_NO_MATCH).  out_* have capacity `out_capacity` >= total left rows. */
@@ -287,6 +290,9 @@ int olap_join_configure(olap_ctx* ctx, int radix_bits_total, int max_bits_per_pa
  *                      lines, one 1024-thread workgroup per CU (default) | 1 claiming pass only | 2 capacity pass only
  *                      | 0 the write-combining kernels
  *   ring_tpt           8 (default) | 4 tuples per producer thread and tile of the ring scatter
+ *   broadcast_join     1 a right table of <= 6144 rows (one LDS hash table) is joined WITHOUT partitioning: every workgroup
+ *                      builds the whole table and streams its share of the left columns; the result keeps the left row
+ *                      order (default; only with the automatic radix plan) | 0 always partition
  *   ring_full_tiles    1 column input whose batches are all whole 4096-row tiles in 16-byte aligned buffers is read by a
  *                      loader without the ragged fallback (keeps the prefetch asynchronous; default) | 0 generic loader
  *   ring_interleave    -1 automatic (default: pass 0's column tiles are dealt to the workgroups round-robin with the

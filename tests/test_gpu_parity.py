@@ -910,6 +910,94 @@ def test_join_selection_vectors(dev, golden, space):
     np.testing.assert_array_equal(c, golden["join_b_out_x"])
 
 
+@pytest.mark.parametrize("space", ["device", "host"])
+@pytest.mark.parametrize("nr", [1, 37, 4096, 6144, 6145])
+def test_join_small_build_side_broadcast(dev, space, nr):
+    """A right table of <= 6144 rows (one LDS table) is joined without partitioning (k_join_broadcast): stats.passes == 0,
+    rows in LEFT ROW ORDER; 6145 rows take the partitioned path again.  Ragged
+    and empty left batches, an unaligned device slice, the key 0xFFFFFFFF (the table's empty marker) on both sides, a
+    duplicate build key (counted once, the later value wins as in hashtable.c:133 -- here both carry the same x), payloads
+    and selection vectors, misses as error and dropped (inner join).  Everything against the oracle / numpy."""
+    o = _ops()
+    rng = np.random.default_rng(1000 + nr)
+    pk = rng.choice(1 << 32, size=nr, replace=False).astype(np.uint32)
+    if nr >= 37:
+        pk[5] = 0xFFFFFFFF
+    x = rng.integers(0, 1 << 32, size=nr, dtype=np.uint32)
+    sizes = [70001, 0, 4096, 8192 * 5 + 3, 1, 300000]
+    nl = sum(sizes)
+    fk = pk[rng.integers(0, nr, size=nl)]
+    y = rng.integers(0, 1 << 32, size=nl, dtype=np.uint32)
+    cut = lambda a, sz: np.split(a, np.cumsum(sz)[:-1])
+    keep = []
+
+    def wrap(a):
+        if space == "host":
+            return a
+        if a.size and a.size % 2 == 1:   # an odd-sized batch lives one element into its allocation: 4-byte aligned only
+            whole = dev.to_device(np.concatenate([a[:1], a]))
+            keep.append(whole)
+            return o.DeviceArray(whole.ptr + 4, a.size, "uint32")
+        return dev.to_device(a)
+
+    rsz = [nr] if nr < 100 else [nr // 3, nr - nr // 3]
+    left = [(wrap(k), wrap(p)) for k, p in zip(cut(fk, sizes), cut(y, sizes))]
+    right = [(wrap(k), wrap(p)) for k, p in zip(cut(pk, rsz), cut(x, rsz))]
+    get = (lambda a: np.asarray(a)) if space == "host" else dev.to_host
+    lut = dict(zip(pk.tolist(), x.tolist()))
+    exp_x = np.array([lut[k] for k in fk.tolist()], dtype=np.uint32)
+    j = o.JoinGpu(dev, left, right).Prepare()
+    r = j.Run()
+    ofk, oy, ox = get(r["fk"]), get(r["y"]), get(r["x"])
+    if nr <= 6144:
+        assert j.stats["passes"] == 0 and j.stats["nr_partitions"] == 1 and dev.phase_kernel("join-probe") == "olap::k_join_broadcast", j.stats
+        np.testing.assert_array_equal(ofk, fk)      # left row order
+        np.testing.assert_array_equal(oy, y)
+        np.testing.assert_array_equal(ox, exp_x)
+    else:
+        assert j.stats["passes"] >= 1 and j.stats["nr_partitions"] >= 2, j.stats
+        for a, b in zip(sort_rows(ofk, oy, ox), sort_rows(fk, y, exp_x)):
+            np.testing.assert_array_equal(a, b)
+    assert j.stats["missing_keys"] == 0 and j.stats["duplicate_keys"] == 0 and j.stats["max_build_rows"] <= nr
+    # the same rows when partitioning is forced
+    dev.set_tuning("broadcast_join", 0)
+    try:
+        r2 = o.JoinGpu(dev, left, right).Prepare().Run()
+    finally:
+        dev.set_tuning("broadcast_join", 1)
+    for a, b in zip(sort_rows(get(r2["fk"]), get(r2["y"]), get(r2["x"])), sort_rows(fk, y, exp_x)):
+        np.testing.assert_array_equal(a, b)
+    # selection vectors
+    js = o.JoinGpu(dev, [k for k, _ in left], [k for k, _ in right], select=True).Prepare()
+    rs = js.Run()
+    sfk, lrow, rrow = get(rs["fk"]), get(rs["y"]), get(rs["x"])
+    np.testing.assert_array_equal(fk[lrow], sfk)
+    np.testing.assert_array_equal(pk[rrow], sfk)
+    np.testing.assert_array_equal(np.sort(lrow), np.arange(nl, dtype=np.uint32))
+    if nr <= 6144:
+        np.testing.assert_array_equal(lrow, np.arange(nl, dtype=np.uint32))
+    if nr >= 37:
+        # a duplicate build key and foreign keys without a match
+        pk2, x2 = np.concatenate([pk, pk[7:8]]), np.concatenate([x, x[7:8]])
+        fk2 = fk.copy()
+        miss = rng.choice(nl, size=1000, replace=False)
+        absent = np.setdiff1d(rng.integers(0, 1 << 32, size=4000, dtype=np.uint64).astype(np.uint32), pk)[:1000]
+        fk2[miss] = absent
+        left2 = [(wrap(k), wrap(p)) for k, p in zip(cut(fk2, sizes), cut(y, sizes))]
+        right2 = [(wrap(pk2), wrap(x2))]
+        if nr + 1 <= 6144:
+            with pytest.raises(o.OlapError):
+                o.JoinGpu(dev, left2, right2).Prepare().Run()
+            jd = o.JoinGpu(dev, left2, right2, drop_unmatched=True).Prepare()
+            rd = jd.Run()
+            assert jd.stats["passes"] == 0 and jd.stats["duplicate_keys"] == 1 and jd.stats["missing_keys"] == 1000, jd.stats
+            hit = np.ones(nl, dtype=bool)
+            hit[miss] = False
+            np.testing.assert_array_equal(get(rd["fk"]), fk2[hit])      # inner join, left order preserved
+            np.testing.assert_array_equal(get(rd["y"]), y[hit])
+            np.testing.assert_array_equal(get(rd["x"]), exp_x[hit])
+
+
 def test_join_many_short_batches_scratch_sizing(dev):
     """24 x 50021-row batches: every batch rounds up to whole 4096-row tiles, so pass 0 has far
     more tiles than rows / 8192 -- the histogram matrix must be sized for that."""
