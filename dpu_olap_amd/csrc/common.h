@@ -91,6 +91,7 @@ struct olap_ctx {
   int wc_geometry = 2;     // 2: passes of <= 512 buckets use 512-thread workgroups on 4096-tuple tiles, two per CU
   int capacity_mode = 1;   // last radix pass without histogram (fixed-capacity regions + exact fallback)
   int ring_scatter = 3;    // bit 0: claiming pass, bit 1: capacity pass: passes of <= 512 buckets run the ring scatter (ring_scatter.h): 128-byte lines, one workgroup per CU
+  int filter_whole_batches = 2;  // filter: from this many long batches per CU on, one workgroup walks a whole batch (no count pass); 0 off
   int broadcast_join = 1;  // a right table that fits one LDS table (<= 6144 rows) is joined without partitioning
   int probe_run = 1;       // direct-table probe: consecutive partitions per workgroup turn
   int ring_full_tiles = 1; // ring scatter from columns: the straight-line loader when all batches are whole aligned tiles

@@ -820,6 +820,10 @@ int olap_set_tuning(olap_ctx* ctx, const char* key, int value) {
     ctx->ring_scatter = value;
     return OLAP_OK;
   }
+  if (!std::strcmp(key, "filter_whole_batches")) {
+    ctx->filter_whole_batches = value < 0 ? 0 : value;  // 0 off, N: from N long batches per CU on
+    return OLAP_OK;
+  }
   if (!std::strcmp(key, "broadcast_join")) {
     ctx->broadcast_join = value != 0;
     return OLAP_OK;

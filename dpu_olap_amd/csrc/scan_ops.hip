@@ -75,7 +75,18 @@ __global__ __launch_bounds__(kBlock) void k_sum(ColView v, const void* const* pt
 #pragma unroll
         for (int k = 0; k < E; ++k) acc += (ACC)vec_get<T>(x[j], k);
     } else {
-      for (uint32_t i = threadIdx.x; i < n; i += kBlock) acc += (ACC)gload_t(p + i);
+      // a batch's last (or only) tile, or a buffer that is only element-aligned: 16-byte loads over the aligned
+      // middle, scalars at both ends (batches shorter than a tile are all "last tiles")
+      const uint32_t head = min(n, (uint32_t)(((16 - (((uintptr_t)p) & 15)) & 15) / sizeof(T)));
+      const uint32_t nvec = (n - head) / E;
+      const V* pv = (const V*)(p + head);
+      for (uint32_t i = threadIdx.x; i < head; i += kBlock) acc += (ACC)gload_t(p + i);
+      for (uint32_t i = threadIdx.x; i < nvec; i += kBlock) {
+        const V x = gload_vec16(pv + i);
+#pragma unroll
+        for (int k = 0; k < E; ++k) acc += (ACC)vec_get<T>(x, k);
+      }
+      for (uint32_t i = head + nvec * E + threadIdx.x; i < n; i += kBlock) acc += (ACC)gload_t(p + i);
     }
   }
   __shared__ unsigned long long s_part[kBlock / kWave];
@@ -596,6 +607,12 @@ static int run_filter(olap_ctx* ctx, const void* const* ptrs, const uint64_t* ro
       s = align_up(s ? s : 1, TILE);
       seg_rows = (uint32_t)(s < TILE ? TILE : (s > 16 * TILE ? 16 * TILE : s));
     }
+    // Enough LONG batches to occupy the chip on their own (filter_whole_batches per CU, default 2): one workgroup walks a
+    // whole batch with its running offset -- one pass over the data (5 B per row at s = 0.25) instead of count + scan +
+    // compact (9 B).  2^30 rows in 512 batches: 1.15 ms against 1.84 ms.
+    if (max_rows > seg_rows && ctx->filter_whole_batches > 0 && cnt >= (uint64_t)ctx->compute_units * ctx->filter_whole_batches &&
+        max_rows < (1ull << 31))
+      seg_rows = (uint32_t)align_up(max_rows, TILE);
     const bool multi_seg = max_rows > seg_rows;
     const void* const* cols[1] = {ptrs + b0};
     uint64_t n_seg_est = 0;

@@ -290,6 +290,8 @@ int olap_join_configure(olap_ctx* ctx, int radix_bits_total, int max_bits_per_pa
  *                      lines, one 1024-thread workgroup per CU (default) | 1 claiming pass only | 2 capacity pass only
  *                      | 0 the write-combining kernels
  *   ring_tpt           8 (default) | 4 tuples per producer thread and tile of the ring scatter
+ *   filter_whole_batches N filter: from N batches per CU on (default 2), a batch longer than 64 Ki rows is still walked by ONE
+ *                      workgroup (one pass over the data) | 0 always count + scan + compact over 64 Ki-row segments
  *   broadcast_join     1 a right table of <= 6144 rows (one LDS hash table) is joined WITHOUT partitioning: every workgroup
  *                      builds the whole table and streams its share of the left columns; the result keeps the left row
  *                      order (default; only with the automatic radix plan) | 0 always partition
