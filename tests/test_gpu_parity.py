@@ -89,6 +89,39 @@ def test_filter_many_batches_device_and_unaligned(dev):
         np.testing.assert_array_equal(dev.to_host(res[b]), oracle.filter_lt(v[b * rows + 1:(b + 1) * rows + 1], 1 << 30))
 
 
+@pytest.mark.parametrize("t", ["u32", "i64"])
+def test_filter_long_batches_one_workgroup_each(dev, t):
+    """Batches longer than a 64 Ki-row segment: with >= 2 of them per CU one workgroup walks a whole batch with its
+    running offset (no count pass, timer phase filter-count absent); with the knob at 0, or with few batches, count +
+    scan + compact.  Ragged lengths, an empty batch, an unaligned slice; same rows either way (oracle)."""
+    o = _ops()
+    rng = np.random.default_rng(21)
+    dt = TYPES[t]
+    nb = 2 * dev.device_info()["compute_units"] + 5
+    lens = [65536 + 4096 * (b % 5) + (b % 7) for b in range(nb)]
+    lens[3], lens[4] = 0, 300001
+    hi = 1 << 32 if dt in (np.uint32, np.uint64) else 1 << 31
+    whole = rng.integers(0, hi, size=sum(lens) + 1, dtype=np.int64).astype(dt)
+    d = dev.to_device(whole)
+    w = np.dtype(dt).itemsize
+    starts = np.concatenate([[0], np.cumsum(lens)])
+    ins = [o.DeviceArray(d.ptr + w * int(starts[b] + (1 if b % 2 else 0)), lens[b], np.dtype(dt).name) for b in range(nb)]   # odd batches one element off
+    host = [whole[int(starts[b] + (1 if b % 2 else 0)):][:lens[b]] for b in range(nb)]
+    for knob, few in ((2, False), (0, False), (2, True)):
+        dev.set_tuning("filter_whole_batches", knob)
+        try:
+            f = o.FilterGpu(dev, ins[:9] if few else ins).Prepare()
+            res = f.GetResult()
+            timers = f.Timers()
+        finally:
+            dev.set_tuning("filter_whole_batches", 2)
+        assert bool(timers.get("filter-count", 0)) == (knob == 0 or few), timers
+        for b in range(len(res)):
+            if b < 12 or b % 37 == 0:
+                np.testing.assert_array_equal(dev.to_host(res[b]), oracle.filter_lt(host[b], 1 << 30))
+        assert sum(r.rows for r in res) == sum(oracle.filter_lt(h, 1 << 30).size for h in host[:len(res)])
+
+
 def test_filter_empty_inputs(dev):
     o = _ops()
     assert o.FilterGpu(dev, []).Prepare().Run() == 0
