@@ -555,6 +555,7 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
   uint64_t need = column_set_bytes(lrows, lnb, l_pay ? 2 : 1, eb, in_mem) + column_set_bytes(rrows, rnb, r_pay ? 2 : 1, eb, in_mem) +
                   side_scratch_bytes(ctx, NL, lnb, plan, in.l_pre) + side_scratch_bytes(ctx, NR, rnb, plan, in.r_pre) +
                   align_up((lt_tuples + 2) * 8, 256) + align_up((rt_tuples + 2) * 8, 256) + 8192;
+  need += align_up((NL / kProbeSlice + 2) * 8, 256) + 256;  // probe slice list
   if (plan.passes >= 2) need += align_up((tmp_tuples + 2) * 8, 256);
   if (plan.passes >= 3) need += align_up((maxN + 2) * 8, 256);
   if (out_mem == OLAP_MEM_HOST) need += 3 * align_up(NL * 4 + 4, 256);
@@ -625,15 +626,25 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
     const uintptr_t a_fk = (uintptr_t)d_fk & 7, a_y = (uintptr_t)d_y & 7, a_x = (uintptr_t)d_x & 7;
     const uint32_t pair_ok = (a_fk | a_y | a_x) == 0 ? 1u : (a_fk == 4 && a_y == 4 && a_x == 4) ? 2u : 0u;
     ctx->phase_kernel[PH_JOIN_PROBE] = direct ? "olap::k_join_probe_direct" : "olap::k_join_probe";
+    // probe partitions longer than one slice (skew: a hot foreign key) become several work items
+    ProbeSlices slices{nullptr, nullptr, 0};
+    if (ctx->probe_slices) {
+      slices.capacity = (uint32_t)std::min<uint64_t>(NL / kProbeSlice + 1, 0xFFFFFFFFull);
+      slices.list = (uint2*)ws_alloc(ctx, (uint64_t)slices.capacity * 8);
+      slices.count = (uint32_t*)ws_alloc(ctx, 16);
+      if (!slices.list || !slices.count) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (probe slices)");
+      OLAP_HIP(ctx, hipMemsetAsync(slices.count, 0, 16, ctx->stream));
+      hipLaunchKernelGGL(k_probe_slices, dim3((P + 255) / 256), dim3(256), 0, ctx->stream, lv, P, slices);
+    }
     if (direct) {
       uint64_t dgrid = (uint64_t)ctx->compute_units * 8;
       if (dgrid > P) dgrid = P;
       const uint32_t run = (uint32_t)std::max(1, ctx->probe_run);
       hipLaunchKernelGGL(k_join_probe_direct, dim3((unsigned)dgrid), dim3(kDBlock), 0, ctx->stream, rv, lv, P, run, table_bits,
-                         (uint32_t)ctx->hash_skip_bits, d_fk, d_y, d_x, pair_ok, d_cnt, miss_bits);
+                         (uint32_t)ctx->hash_skip_bits, d_fk, d_y, d_x, pair_ok, d_cnt, miss_bits, slices);
     } else {
       hipLaunchKernelGGL(k_join_probe, dim3((unsigned)grid), dim3(kJBlock), 0, ctx->stream, rv, lv, P, d_fk, d_y, d_x,
-                         pair_ok, d_cnt, miss_bits);
+                         pair_ok, d_cnt, miss_bits, slices);
     }
     OLAP_HIP(ctx, hipGetLastError());
   }
@@ -822,6 +833,10 @@ int olap_set_tuning(olap_ctx* ctx, const char* key, int value) {
   }
   if (!std::strcmp(key, "filter_whole_batches")) {
     ctx->filter_whole_batches = value < 0 ? 0 : value;  // 0 off, N: from N long batches per CU on
+    return OLAP_OK;
+  }
+  if (!std::strcmp(key, "probe_slices")) {
+    ctx->probe_slices = value != 0;
     return OLAP_OK;
   }
   if (!std::strcmp(key, "broadcast_join")) {

@@ -23,10 +23,34 @@ struct PartView {
   uint32_t cap;
 };
 
+// A probe partition far larger than the others (one hot foreign key) would be streamed by ONE workgroup while the rest of
+// the chip idles (2^27 left rows, half of them one key: 52 ms of probe).  The probe side of a partition is therefore cut
+// into slices of kProbeSlice rows: slice 0 is handled where the partition is, every further slice is a work item of its own
+// -- (partition, slice) pairs listed by k_probe_slices, taken up by the probe kernels' workgroups after their partitions;
+// each rebuilds the partition's table (the build side is not the skewed one) and probes its slice.  Uniform data has no
+// partition beyond one slice: the list stays empty.
+constexpr uint32_t kProbeSlice = 1u << 16;
+struct ProbeSlices {
+  uint2* list;          // (partition, slice >= 1)
+  uint32_t* count;      // entries wanted (may exceed capacity: clamp)
+  uint32_t capacity;
+};
+
+__global__ __launch_bounds__(256) void k_probe_slices(PartView LV, uint32_t nparts, ProbeSlices ps) {
+  const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= nparts) return;
+  const uint64_t n_l = LV.cap ? (uint64_t)LV.cnt[p] : LV.off[p + 1] - LV.off[p];
+  const uint64_t ns = (n_l + kProbeSlice - 1) / kProbeSlice;
+  for (uint64_t sl = 1; sl < ns; ++sl) {
+    const uint32_t at = atomicAdd(ps.count, 1u);
+    if (at < ps.capacity) ps.list[at] = make_uint2(p, (uint32_t)sl);
+  }
+}
+
 __global__ __launch_bounds__(kJBlock, 4) void k_join_probe(PartView RV, PartView LV, uint32_t nparts,
                                                            uint32_t* out_fk, uint32_t* out_y,
                                                            uint32_t* out_x, uint32_t pair_store_ok,
-                                                           unsigned long long* counters, uint32_t* miss_bits) {
+                                                           unsigned long long* counters, uint32_t* miss_bits, ProbeSlices slices) {
   const uint2* R = RV.t;
   const uint2* L = LV.t;
   __shared__ uint32_t s_keys[kSlots];
@@ -34,7 +58,7 @@ __global__ __launch_bounds__(kJBlock, 4) void k_join_probe(PartView RV, PartView
   __shared__ uint32_t s_sp[2];  // the one key equal to the empty marker: {present, value}
   uint32_t my_miss = 0, my_dup = 0;
   uint64_t my_max = 0;
-  for (uint32_t p = blockIdx.x; p < nparts; p += gridDim.x) {
+  auto body = [&](const uint32_t p, const uint32_t slice) {
     const uint64_t rlo = RV.cap ? (uint64_t)p * RV.cap : RV.off[p];
     const uint64_t rhi = RV.cap ? rlo + RV.cnt[p] : RV.off[p + 1];
     const uint64_t llo = LV.cap ? (uint64_t)p * LV.cap : LV.off[p];
@@ -46,11 +70,14 @@ __global__ __launch_bounds__(kJBlock, 4) void k_join_probe(PartView RV, PartView
     // aligned, 2 = they all start at 4 mod 8 (a slice of a larger result), 0 = mixed -> 4-byte stores
     const uint32_t pair_store = pair_store_ok && ((delta + (pair_store_ok >> 1)) & 1) == 0;
     if (n_r > my_max) my_max = n_r;
-    if (n_l == 0) continue;
+    if (n_l == 0) return;
     if (n_r > kTableCap) {
-      if (threadIdx.x == 0) atomicAdd(&counters[2], 1ull);
-      continue;
+      if (threadIdx.x == 0 && slice == 0) atomicAdd(&counters[2], 1ull);
+      return;
     }
+    // this work item's share of the probe side (slice 0 with the partition, the others from the slice list)
+    const uint64_t lb = llo + (uint64_t)slice * kProbeSlice, le = slices.count ? min(lhi, lb + kProbeSlice) : lhi;  // (no slice list: all of it)
+    if (lb >= le) return;
     for (uint32_t i = threadIdx.x; i < kSlots; i += kJBlock) s_keys[i] = kEmpty;
     if (threadIdx.x == 0) s_sp[0] = 0;
     __syncthreads();
@@ -77,14 +104,14 @@ __global__ __launch_bounds__(kJBlock, 4) void k_join_probe(PartView RV, PartView
             if (i0 + h < rlo || i0 + h >= rhi) continue;
             if (k == kEmpty) {
               s_sp[1] = val;
-              if (atomicExch(&s_sp[0], 1u)) ++my_dup;
+              if (atomicExch(&s_sp[0], 1u) && slice == 0) ++my_dup;
             } else {
               uint32_t slot = wang_hash(k) & (kSlots - 1);
               for (uint32_t step = 0; step < kSlots; ++step) {
                 const uint32_t old = atomicCAS(&s_keys[slot], kEmpty, k);
                 if (old == kEmpty || old == k) {  // free cell, or equal key overwrites (hashtable.c:133)
                   s_vals[slot] = val;
-                  if (old == k) ++my_dup;
+                  if (old == k && slice == 0) ++my_dup;
                   break;
                 }
                 slot = (slot + 1) & (kSlots - 1);
@@ -97,8 +124,8 @@ __global__ __launch_bounds__(kJBlock, 4) void k_join_probe(PartView RV, PartView
     __syncthreads();
     // probe (hash_probe.c:26-36) fused with the take of the right payload
     {
-      const uint64_t a = llo & ~1ull;
-      const uint64_t span = lhi - a;
+      const uint64_t a = lb & ~1ull;
+      const uint64_t span = le - a;
       for (uint64_t base = 0; base < span; base += kJBlock * 2 * kJU) {
         uint4 v[kJU];
 #pragma unroll
@@ -115,7 +142,7 @@ __global__ __launch_bounds__(kJBlock, 4) void k_join_probe(PartView RV, PartView
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             const uint32_t k = h ? v[u].z : v[u].x;
-            ok[h] = i0 + h >= llo && i0 + h < lhi;
+            ok[h] = i0 + h >= lb && i0 + h < le;
             if (!ok[h]) continue;
             bool hit = false;
             if (k == kEmpty) {
@@ -161,7 +188,10 @@ __global__ __launch_bounds__(kJBlock, 4) void k_join_probe(PartView RV, PartView
       }
     }
     __syncthreads();
-  }
+  };
+  for (uint32_t p = blockIdx.x; p < nparts; p += gridDim.x) body(p, 0u);
+  const uint32_t n_extra = slices.count ? min(*slices.count, slices.capacity) : 0u;
+  for (uint32_t w = blockIdx.x; w < n_extra; w += gridDim.x) body(slices.list[w].x, slices.list[w].y);
   const uint64_t wm = wave_reduce_add((uint64_t)my_miss);
   const uint64_t wd = wave_reduce_add((uint64_t)my_dup);
   if (lane_id() == 0) {
@@ -310,7 +340,7 @@ __global__ __launch_bounds__(kDBlock, 4) void k_join_probe_direct(PartView RV, P
                                                                uint32_t table_bits, uint32_t skip_bits, uint32_t* out_fk,
                                                                uint32_t* out_y, uint32_t* out_x,
                                                                uint32_t pair_store_ok, unsigned long long* counters,
-                                                               uint32_t* miss_bits) {
+                                                               uint32_t* miss_bits, ProbeSlices slices) {
   __shared__ uint32_t s_vals[kDSlots];
   __shared__ uint32_t s_used[kDSlots / 32];
   const uint2* R = RV.t;
@@ -319,10 +349,7 @@ __global__ __launch_bounds__(kDBlock, 4) void k_join_probe_direct(PartView RV, P
   uint32_t my_miss = 0, my_dup = 0, my_foreign = 0;
   uint64_t my_max = 0;
   const uint32_t top_shift = skip_bits ? 32u - skip_bits : 0u;
-  // partitions are dealt to the workgroups in runs of `run` consecutive ones (1: round-robin)
-  const uint32_t n_runs = (nparts + run - 1) / run;
-  for (uint32_t q = blockIdx.x * run; q < n_runs * run; q += gridDim.x * run)
-  for (uint32_t p = q; p < min(q + run, nparts); ++p) {
+  auto body = [&](const uint32_t p, const uint32_t slice) {
     const uint64_t rlo = RV.cap ? (uint64_t)p * RV.cap : RV.off[p];
     const uint64_t rhi = RV.cap ? rlo + RV.cnt[p] : RV.off[p + 1];
     const uint64_t llo = LV.cap ? (uint64_t)p * LV.cap : LV.off[p];
@@ -333,7 +360,10 @@ __global__ __launch_bounds__(kDBlock, 4) void k_join_probe_direct(PartView RV, P
     // aligned, 2 = they all start at 4 mod 8 (a slice of a larger result), 0 = mixed -> 4-byte stores
     const uint32_t pair_store = pair_store_ok && ((delta + (pair_store_ok >> 1)) & 1) == 0;
     if (n_r > my_max) my_max = n_r;
-    if (n_l == 0) continue;
+    if (n_l == 0) return;
+    // this work item's share of the probe side (slice 0 with the partition, the others from the slice list)
+    const uint64_t lb = llo + (uint64_t)slice * kProbeSlice, le = slices.count ? min(lhi, lb + kProbeSlice) : lhi;  // (no slice list: all of it)
+    if (lb >= le) return;
     const uint32_t top_ref = (skip_bits && n_r) ? wang_hash(R[rlo].x) >> top_shift : 0u;  // leading bits every tuple here must share
     for (uint32_t i = threadIdx.x; i < (slots + 31) / 32; i += kDBlock) s_used[i] = 0;
     __syncthreads();
@@ -365,7 +395,7 @@ __global__ __launch_bounds__(kDBlock, 4) void k_join_probe_direct(PartView RV, P
             if (skip_bits && (hk >> top_shift) != top_ref) ++my_foreign;
             const uint32_t slot = hk & smask;
             const uint32_t bit = 1u << (slot & 31);
-            if (atomicOr(&s_used[slot >> 5], bit) & bit) ++my_dup;  // equal key overwrites (hashtable.c:133)
+            if ((atomicOr(&s_used[slot >> 5], bit) & bit) && slice == 0) ++my_dup;  // equal key overwrites (hashtable.c:133)
             s_vals[slot] = val;
           }
         }
@@ -373,8 +403,8 @@ __global__ __launch_bounds__(kDBlock, 4) void k_join_probe_direct(PartView RV, P
     }
     __syncthreads();
     {  // probe + take of the right payload
-      const uint64_t a = llo & ~1ull;
-      const uint64_t span = lhi - a;
+      const uint64_t a = lb & ~1ull;
+      const uint64_t span = le - a;
       for (uint64_t base = 0; base < span; base += kDBlock * 2 * kJU) {
         uint4 v[kJU];
 #pragma unroll
@@ -397,7 +427,7 @@ __global__ __launch_bounds__(kDBlock, 4) void k_join_probe_direct(PartView RV, P
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             const uint32_t k = h ? v[u].z : v[u].x;
-            ok[h] = i0 + h >= llo && i0 + h < lhi;
+            ok[h] = i0 + h >= lb && i0 + h < le;
             if (!ok[h]) continue;
             const uint32_t hk = wang_hash(k);
             if (skip_bits && n_r && (hk >> top_shift) != top_ref) ++my_foreign;
@@ -430,7 +460,13 @@ __global__ __launch_bounds__(kDBlock, 4) void k_join_probe_direct(PartView RV, P
       }
     }
     __syncthreads();
-  }
+  };
+  // partitions are dealt to the workgroups in runs of `run` consecutive ones (1: round-robin)
+  const uint32_t n_runs = (nparts + run - 1) / run;
+  for (uint32_t q = blockIdx.x * run; q < n_runs * run; q += gridDim.x * run)
+    for (uint32_t p = q; p < min(q + run, nparts); ++p) body(p, 0u);
+  const uint32_t n_extra = slices.count ? min(*slices.count, slices.capacity) : 0u;
+  for (uint32_t w = blockIdx.x; w < n_extra; w += gridDim.x) body(slices.list[w].x, slices.list[w].y);
   const uint64_t wm = wave_reduce_add((uint64_t)my_miss);
   const uint64_t wd = wave_reduce_add((uint64_t)my_dup);
   const uint64_t wf = wave_reduce_add((uint64_t)my_foreign);

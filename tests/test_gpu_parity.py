@@ -1031,6 +1031,56 @@ def test_join_small_build_side_broadcast(dev, space, nr):
             np.testing.assert_array_equal(get(rd["x"]), exp_x[hit])
 
 
+@pytest.mark.parametrize("plan", ["probing", "direct"])
+def test_join_hot_foreign_key_probe_slices(dev, plan):
+    """A probe partition far beyond 64 Ki rows (40 % of the left rows carry ONE foreign key, another 10 % a key WITHOUT a
+    match): the partition is cut into slices that several workgroups take up (k_probe_slices), each rebuilding the
+    partition's table.  Same rows as with probe_slices = 0 and as numpy; misses inside the hot slices are reported /
+    dropped correctly; duplicates on the build side are counted once, not once per slice."""
+    o = _ops()
+    rng = np.random.default_rng(77)
+    nr, nl, nb = 1 << 20, 3_000_000, 5
+    pk = rng.permutation(nr).astype(np.uint32) * np.uint32(2)              # even keys
+    x = rng.integers(0, 1 << 32, size=nr, dtype=np.uint32)
+    fk = pk[rng.integers(0, nr, size=nl)]
+    u = rng.random(nl)
+    fk[u < 0.4] = pk[123]                                                  # the hot key
+    fk[(u >= 0.4) & (u < 0.5)] = np.uint32(7)                              # odd: not a primary key
+    y = np.arange(nl, dtype=np.uint32)
+    pk2, x2 = np.concatenate([pk, pk[123:124]]), np.concatenate([x, x[123:124]])   # the hot key twice on the build side
+    cut = lambda a: np.array_split(a, nb)
+    left = [(dev.to_device(k), dev.to_device(p)) for k, p in zip(cut(fk), cut(y))]
+    right = [(dev.to_device(k), dev.to_device(p)) for k, p in zip(cut(pk2), cut(x2))]
+    lut = np.zeros(2 * nr, np.uint32)
+    lut[pk] = x
+    keep = fk % 2 == 0
+    results = []
+    for knob in (1, 0):
+        dev.set_tuning("probe_slices", knob)
+        if plan == "direct":
+            dev.join_configure(18, 9)       # 14 hash bits remain: direct-address table
+        else:
+            dev.join_configure(8, 8)        # probing table, 4096 build rows per partition
+        try:
+            with pytest.raises(o.OlapError):
+                o.JoinGpu(dev, left, right).Prepare().Run()
+            j = o.JoinGpu(dev, left, right, drop_unmatched=True).Prepare()
+            r = j.Run()
+        finally:
+            dev.set_tuning("probe_slices", 1)
+            dev.join_configure(-1, 0)
+        assert j.stats["missing_keys"] == int((~keep).sum()) and j.stats["duplicate_keys"] == 1, j.stats
+        assert ("direct" in dev.phase_kernel("join-probe")) == (plan == "direct")
+        ofk, oy, ox = dev.to_host(r["fk"]), dev.to_host(r["y"]), dev.to_host(r["x"])
+        assert ofk.size == int(keep.sum())
+        np.testing.assert_array_equal(np.sort(oy), y[keep])
+        np.testing.assert_array_equal(fk[oy], ofk)
+        np.testing.assert_array_equal(lut[ofk], ox)
+        results.append(sort_rows(ofk, oy, ox))
+    for a, b in zip(*results):
+        np.testing.assert_array_equal(a, b)
+
+
 def test_join_many_short_batches_scratch_sizing(dev):
     """24 x 50021-row batches: every batch rounds up to whole 4096-row tiles, so pass 0 has far
     more tiles than rows / 8192 -- the histogram matrix must be sized for that."""
