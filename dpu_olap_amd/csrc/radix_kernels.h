@@ -316,6 +316,41 @@ __device__ __forceinline__ void load_tile_full(const PassSrc& s, uint64_t tile, 
   }
 }
 
+// Rank of a tuple inside its bucket for the current tile: cl[b]++ in LDS.  When many lanes of a wave hold the SAME bucket
+// (a hot key) the hardware serialises their atomics (2^27 rows, half of them one key: histogram 0.44 -> 3.8 ms, scatter
+// 1.1 -> 9.1 ms).  Such a bucket is counted once per wave instead: the lanes compare their bucket with a candidate -- the
+// bucket that was hot at the previous call, else the first valid lane's -- and if >= 8 agree, one lane adds the count
+// and every one of them takes base + its position among them.  A wave looks for a hot bucket once per tile (look = true on
+// its first tuple slot) and keeps testing every slot while one is hot; without one the cost is a readfirstlane per slot.
+struct HotGuess {
+  uint32_t b = 0xFFFFFFFFu;
+};
+__device__ __forceinline__ uint32_t lds_rank(uint32_t* cl, uint32_t b, bool valid, HotGuess& g, bool look) {
+  // no bucket known to be hot and not the call that looks for one (once per tile): the plain atomic
+  const uint32_t gb = (uint32_t)__builtin_amdgcn_readfirstlane((int)g.b);  // (one lane's guess: after a divergent edge tile they may differ)
+  if (gb == 0xFFFFFFFFu && !look) return valid ? atomicAdd(&cl[b], 1u) : 0u;
+  const unsigned long long act = __ballot(valid);
+  if (!act) return 0;
+  const int lead = __ffsll((long long)act) - 1;
+  const uint32_t cand = gb != 0xFFFFFFFFu ? gb : (uint32_t)__shfl((int)b, lead, kWave);
+  const bool same = valid && b == cand;
+  const unsigned long long m = __ballot(same);
+  uint32_t r = 0;
+  if (__popcll(m) >= 8) {
+    const int first = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if ((int)lane_id() == first) base = atomicAdd(&cl[cand], (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, first, kWave);
+    g.b = cand;
+    if (same) r = base + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull));
+    else if (valid) r = atomicAdd(&cl[b], 1u);
+  } else {
+    g.b = 0xFFFFFFFFu;  // not hot (any more)
+    if (valid) r = atomicAdd(&cl[b], 1u);
+  }
+  return r;
+}
+
 // ------------------------------------------------------------------ hist
 template <int SRC, int BLOCK, int TILE = kPTile>
 __global__ __launch_bounds__(BLOCK) void k_part_hist(PassSrc s, uint32_t shift, uint32_t fbits,
@@ -327,13 +362,12 @@ __global__ __launch_bounds__(BLOCK) void k_part_hist(PassSrc s, uint32_t shift, 
   __syncthreads();
   const TileRange r = block_tiles<SRC, TILE>(s);
   ColsCursor cur;
+  HotGuess hot;
   for (uint64_t tile = r.t0; tile < r.t1; ++tile) {
     uint32_t key[TPT], pay[TPT];
     const uint32_t mask = load_tile<SRC, BLOCK, false, TILE>(s, r, tile, cur, key, pay);
 #pragma unroll
-    for (int i = 0; i < TPT; ++i) {
-      if (mask & (1u << i)) atomicAdd(&cl[pass_bucket(s, wang_hash(key[i]), shift, F)], 1u);
-    }
+    for (int i = 0; i < TPT; ++i) (void)lds_rank(cl, pass_bucket(s, wang_hash(key[i]), shift, F), (mask >> i) & 1u, hot, i == 0);
   }
   __syncthreads();
   for (uint32_t b = threadIdx.x; b < F; b += BLOCK) hist[(uint64_t)blockIdx.x * F + b] = cl[b];
@@ -570,6 +604,7 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_wc(PassSrc s, uint32_t s
   uint32_t key[kWTPT], pay[kWTPT], nkey[kWTPT], npay[kWTPT];
   uint32_t mask = 0, nmask = 0;
   ColsCursor cur;
+  HotGuess hot;
   if (r.t0 < r.t1) mask = load_tile<SRC, BLOCK, true, TILE>(s, r, r.t0, cur, key, pay);
   for (uint64_t tile = r.t0; tile < r.t1; ++tile) {
     // (2) bucket + rank of every tuple
@@ -579,19 +614,18 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_wc(PassSrc s, uint32_t s
 #pragma unroll
       for (int i = 0; i < kWTPT; ++i) {
         const uint32_t b = pass_bucket(s, wang_hash(key[i]), shift, F);
-        br[i] = (b << 16) | atomicAdd(&cl[b], 1u);
+        br[i] = (b << 16) | lds_rank(cl, b, true, hot, i == 0);
       }
     } else {
       const uint32_t expect = r.seg & s.chk_mask;
 #pragma unroll
       for (int i = 0; i < kWTPT; ++i) {
-        br[i] = 0;
         const uint32_t h = wang_hash(key[i]);
         if (((h >> s.chk_shift) & s.chk_mask) != expect) mask &= ~(1u << i);  // a filler of the claiming scatter
-        if (mask & (1u << i)) {
-          const uint32_t b = pass_bucket(s, h, shift, F);
-          br[i] = (b << 16) | atomicAdd(&cl[b], 1u);
-        }
+        const bool valid = (mask >> i) & 1u;
+        const uint32_t b = pass_bucket(s, h, shift, F);
+        const uint32_t rk = lds_rank(cl, b, valid, hot, i == 0);
+        br[i] = valid ? (b << 16) | rk : 0u;
       }
     }
     __syncthreads();
