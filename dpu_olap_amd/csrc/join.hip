@@ -755,6 +755,12 @@ static int join_run(olap_ctx* ctx, const JoinIn& jin, uint64_t NL, uint64_t NR, 
     // (one bit MORE than the probing table would need is still the better plan: the same two passes, and a probe that is
     // twice as fast per row -- SF=256: 15.5 -> 10.x ms per join)
     if (ctx->direct_table && dbits >= 1 && dbits <= (int)bits + 1 && (NR >> dbits) >= 2048) bits = (uint32_t)dbits;
+    // Probing table: one bit more (2048 instead of 4096 build rows per 8192-slot table: shorter probe chains) whenever it
+    // does not cost another pass -- SF=64: probe 1.63 -> 1.32 ms, SF=16: 0.46 -> 0.37 ms.
+    if (!(ctx->direct_table && dbits >= 1 && bits == (uint32_t)dbits)) {
+      const int maxb = std::min(ctx->max_bits_per_pass > 0 ? ctx->max_bits_per_pass : kMaxFBits, kMaxFBits);
+      if ((int)(bits + 1 + maxb - 1) / maxb == (int)(bits + maxb - 1) / maxb && (NR >> (bits + 1)) >= 64) ++bits;
+    }
     // A small build side must not leave the probe to a handful of workgroups (one partition = one workgroup at a time;
     // 2^28 x 2^16 rows took 52 ms with the 16 partitions the table size asks for): at least 1024 partitions -- still
     // one pass -- when the probe side is large.
