@@ -121,6 +121,7 @@ static int join64_once(olap_ctx* ctx, const uint64_t* const* lfk, const uint32_t
   uint64_t need = column_set_bytes(lrows, lnb, l_pay ? 2 : 1, eb, in_mem) + column_set_bytes(rrows, rnb, r_pay ? 2 : 1, eb, in_mem) +
                   side_scratch_bytes64(ctx, NL, lnb, plan) + side_scratch_bytes64(ctx, NR, rnb, plan) + align_up((NL + 1) * 16, 256) +
                   align_up((NR + 1) * 16, 256) + 8192;
+  need += align_up((NL / kProbeSlice + 2) * 8, 256) + 256;  // probe slice list
   if (plan.passes >= 2) need += align_up((maxN + 1) * 16, 256);
   if (plan.passes >= 3) need += align_up((maxN + 1) * 16, 256);
   if (out_mem == OLAP_MEM_HOST) need += align_up(NL * 8 + 8, 256) + 2 * align_up(NL * 4 + 4, 256);
@@ -158,8 +159,18 @@ static int join64_once(olap_ctx* ctx, const uint64_t* const* lfk, const uint32_t
     PhaseScope ps(ctx, PH_JOIN_PROBE);
     ctx->phase_kernel[PH_JOIN_PROBE] = "olap::k64_probe";
     const uint64_t grid = std::min<uint64_t>((uint64_t)ctx->compute_units * 8, P);
+    ProbeSlices slices{nullptr, nullptr, 0};  // probe partitions longer than one slice (a hot foreign key) become several work items
+    if (ctx->probe_slices) {
+      slices.capacity = (uint32_t)std::min<uint64_t>(NL / kProbeSlice + 1, 0xFFFFFFFFull);
+      slices.list = (uint2*)ws_alloc(ctx, (uint64_t)slices.capacity * 8);
+      slices.count = (uint32_t*)ws_alloc(ctx, 16);
+      if (!slices.list || !slices.count) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (probe slices)");
+      OLAP_HIP(ctx, hipMemsetAsync(slices.count, 0, 16, ctx->stream));
+      const PartView lv{nullptr, loff, nullptr, nullptr, 0};
+      hipLaunchKernelGGL(k_probe_slices, dim3((P + 255) / 256), dim3(256), 0, ctx->stream, lv, P, slices);
+    }
     hipLaunchKernelGGL(k64_probe, dim3((unsigned)grid), dim3(k64Block), 0, ctx->stream, (const uint4*)Rt, roff, (const uint4*)Lt, loff, P, d_fk,
-                       d_y, d_x, d_cnt, miss_bits);
+                       d_y, d_x, d_cnt, miss_bits, slices);
     OLAP_HIP(ctx, hipGetLastError());
   }
   OLAP_HIP(ctx, hipMemcpyAsync(counters, d_cnt, 32, hipMemcpyDeviceToHost, ctx->stream));

@@ -188,20 +188,23 @@ __global__ __launch_bounds__(k64Block) void k64_scatter(PassSrc s, uint32_t shif
 // counters: [0] missing keys, [1] duplicate build keys, [2] overflowing partitions, [3] max build rows
 __global__ __launch_bounds__(k64Block) void k64_probe(const uint4* R, const uint64_t* roff, const uint4* L, const uint64_t* loff,
                                                        uint32_t nparts, uint64_t* out_fk, uint32_t* out_y, uint32_t* out_x,
-                                                       unsigned long long* counters, uint32_t* miss_bits) {
+                                                       unsigned long long* counters, uint32_t* miss_bits, ProbeSlices slices) {
   __shared__ unsigned long long s_keys[k64Slots];
   __shared__ uint32_t s_vals[k64Slots];
   __shared__ uint32_t s_sp[2];  // the one key equal to the empty marker: {present, value}
   uint32_t my_miss = 0, my_dup = 0;
   uint64_t my_max = 0;
-  for (uint32_t p = blockIdx.x; p < nparts; p += gridDim.x) {
-    const uint64_t rlo = roff[p], rhi = roff[p + 1], llo = loff[p], lhi = loff[p + 1];
+  // (partition, slice of its probe rows): slice 0 with the partition, further slices from the list (probe_kernels.h)
+  auto body = [&](const uint32_t p, const uint32_t slice) {
+    const uint64_t rlo = roff[p], rhi = roff[p + 1], plo = loff[p], phi = loff[p + 1];
     if (rhi - rlo > my_max) my_max = rhi - rlo;
-    if (lhi == llo) continue;
+    if (phi == plo) return;
     if (rhi - rlo > k64TableCap) {
-      if (threadIdx.x == 0) atomicAdd(&counters[2], 1ull);
-      continue;
+      if (threadIdx.x == 0 && slice == 0) atomicAdd(&counters[2], 1ull);
+      return;
     }
+    const uint64_t llo = plo + (uint64_t)slice * kProbeSlice, lhi = slices.count ? min(phi, llo + kProbeSlice) : phi;
+    if (llo >= lhi) return;
     for (uint32_t i = threadIdx.x; i < k64Slots; i += k64Block) s_keys[i] = k64Empty;
     if (threadIdx.x == 0) s_sp[0] = 0;
     __syncthreads();
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(k64Block) void k64_probe(const uint4* R, const uint
       const unsigned long long k = ((unsigned long long)v.y << 32) | v.x;
       if (k == k64Empty) {
         s_sp[1] = v.z;
-        if (atomicExch(&s_sp[0], 1u)) ++my_dup;
+        if (atomicExch(&s_sp[0], 1u) && slice == 0) ++my_dup;
         continue;
       }
       uint32_t slot = ht_hash64(k) & (k64Slots - 1);  // hashtable.c:99-101
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(k64Block) void k64_probe(const uint4* R, const uint
         const unsigned long long old = atomicCAS(&s_keys[slot], k64Empty, k);
         if (old == k64Empty || old == k) {  // free cell, or an equal key overwrites (hashtable.c:133)
           s_vals[slot] = v.z;
-          if (old == k) ++my_dup;
+          if (old == k && slice == 0) ++my_dup;
           break;
         }
         slot = (slot + 1) & (k64Slots - 1);
@@ -255,7 +258,10 @@ __global__ __launch_bounds__(k64Block) void k64_probe(const uint4* R, const uint
       out_x[i] = xv;
     }
     __syncthreads();
-  }
+  };
+  for (uint32_t p = blockIdx.x; p < nparts; p += gridDim.x) body(p, 0u);
+  const uint32_t n_extra = slices.count ? min(*slices.count, slices.capacity) : 0u;
+  for (uint32_t w = blockIdx.x; w < n_extra; w += gridDim.x) body(slices.list[w].x, slices.list[w].y);
   const uint64_t wm = wave_reduce_add((uint64_t)my_miss), wd = wave_reduce_add((uint64_t)my_dup);
   if (lane_id() == 0) {
     if (wm) atomicAdd(&counters[0], (unsigned long long)wm);

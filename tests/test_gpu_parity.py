@@ -1497,6 +1497,40 @@ def test_join_u64_vs_arrow_golden(dev, golden, case, bits, space):
         np.testing.assert_array_equal(g, golden[f"join_{case}_out_{k}"])
 
 
+def test_join_u64_hot_foreign_key_probe_slices(dev):
+    """64-bit keys with a hot foreign key (40 % of 2 M left rows) and a hot key WITHOUT a match (10 %): the hot partitions'
+    probe rows are cut into slices shared by several workgroups (as in the 32-bit kernels).  Rows against numpy; the
+    same with probe_slices = 0; a duplicate build key is counted once."""
+    o = _ops()
+    rng = np.random.default_rng(640)
+    nr, nl = 1 << 19, 2_000_000
+    pk = ((rng.permutation(nr).astype(np.uint64) << np.uint64(30)) | rng.integers(0, 1 << 29, size=nr, dtype=np.uint64)) << np.uint64(1)   # unique, even
+    x = rng.integers(0, 1 << 32, size=nr, dtype=np.uint32)
+    fk = pk[rng.integers(0, nr, size=nl)]
+    u = rng.random(nl)
+    fk[u < 0.4] = pk[77]
+    fk[(u >= 0.4) & (u < 0.5)] = np.uint64(0x123456789ABCDEF1)                # odd: no such primary key
+    y = np.arange(nl, dtype=np.uint32)
+    pk2, x2 = np.concatenate([pk, pk[77:78]]), np.concatenate([x, x[77:78]])
+    keep = (fk & np.uint64(1)) == 0
+    lut = dict(zip(pk.tolist(), x.tolist()))
+    exp_x = np.array([lut[k] for k in fk[keep].tolist()], dtype=np.uint32)
+    cut = lambda a: np.array_split(a, 3)
+    left, right = list(zip(cut(fk), cut(y))), list(zip(cut(pk2), cut(x2)))
+    for knob in (1, 0):
+        dev.set_tuning("probe_slices", knob)
+        try:
+            j = o.JoinGpu(dev, left, right, drop_unmatched=True).Prepare()
+            r = j.Run()
+        finally:
+            dev.set_tuning("probe_slices", 1)
+        assert j.stats["missing_keys"] == int((~keep).sum()) and j.stats["duplicate_keys"] == 1, j.stats
+        np.testing.assert_array_equal(np.sort(r["y"]), y[keep])
+        np.testing.assert_array_equal(fk[r["y"]], r["fk"])
+        order = np.argsort(r["y"])
+        np.testing.assert_array_equal(r["x"][order], exp_x)
+
+
 def test_join_u64_large_vs_oracle_and_error_modes(dev):
     """2^22 x 2^22 rows of 64-bit keys in ragged batches against the oracle's join (same hash, same table semantics);
     then the contract: a missing key is OLAP_ERR_NO_MATCH (or dropped in inner-join mode, order preserved), a
