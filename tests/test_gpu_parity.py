@@ -537,7 +537,8 @@ def test_join_capacity_and_exact_layouts_agree(dev, capacity_mode):
     fk = dev.to_host(out["fk"])
     part = oracle.wang_hash_np(fk) >> np.uint32(32 - sum(j.stats["radix_bits"]))
     assert (np.diff(part.astype(np.int64)) >= 0).all()
-    assert "partition-scatter" in timers
+    # capacity mode on: the histogram-free pair (claiming pass 0 + capacity-layout pass 1); off: histogram + scan + scatter
+    assert ("partition-scatter-capacity" in timers) == bool(capacity_mode) and ("partition-hist" in timers) == (not capacity_mode), timers
     for c in list(cols.values()) + list(out.values()):
         dev.release(o.DeviceArray(c.ptr, 0))
 
