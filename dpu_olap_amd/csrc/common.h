@@ -95,6 +95,7 @@ struct olap_ctx {
   int probe_slices = 1;    // probe partitions longer than 64 Ki rows are shared by several workgroups (skewed foreign keys)
   int broadcast_join = 1;  // a right table that fits one LDS table (<= 6144 rows) is joined without partitioning
   int probe_run = 1;       // direct-table probe: consecutive partitions per workgroup turn
+  int ring_split_ragged = 1; // ring scatter from ragged columns: whole aligned tiles and the rest in two launches (0: one launch, generic loader)
   int ring_full_tiles = 1; // ring scatter from columns: the straight-line loader when all batches are whole aligned tiles
   int claim_weave = 1;     // claiming ring scatter writes woven regions (radix_kernels.h woven_at)
   int ring_interleave = -1; // ring scatter from columns: tiles dealt to the workgroups round-robin in chunks of this many (0: one contiguous run each; -1: automatic)
@@ -181,6 +182,8 @@ struct ColView {
   uint32_t unit_rows;
   uint32_t units_per_batch;  // > 0 when every batch has the same row count
   uint32_t uniform_rows;     // that row count (valid when units_per_batch > 0)
+  const uint64_t* row0;      // optional [nb]: global index of each entry's first row when the entries are PIECES of batches
+                             // (split_column_set); null: row_start[b]
 };
 
 // Host-side staging of a batched column set: builds the device tables (and, for
@@ -189,7 +192,18 @@ struct ColumnSet {
   ColView view{};
   std::vector<const void* const*> dev_ptr_tables;  // one device pointer table per column
   bool full_units = false;  // every batch is a whole number of units and every buffer is 16-byte aligned
+  // host copies (device addresses, rows, element sizes) for views derived from this one (split_column_set)
+  std::vector<std::vector<const void*>> h_ptrs;
+  std::vector<uint64_t> h_rows;
+  std::vector<uint32_t> h_elem;
 };
+
+// Two views of the same buffers: `whole` = of every batch whose buffers are 16-byte aligned, the leading whole units
+// (full_units holds), `rest` = everything else (the tails, and unaligned batches entirely).  Both number their rows
+// globally like `cs` (ColView::row0).  Tables come from the arena / pinned scratch of the current call.
+int split_column_set(olap_ctx* ctx, const ColumnSet& cs, ColumnSet* whole, ColumnSet* rest);
+uint64_t split_column_set_bytes(uint64_t nb, int ncols);
+inline uint64_t split_column_set_pinned(uint64_t nb, int ncols) { return 2 * (nb + 2) * 8 * (3 + (uint64_t)ncols) + 1024; }
 
 // Builds view tables in the arena.  `cols` = ncols arrays of nb host-side pointers.
 // For in_mem == HOST the data is copied to the arena and the tables point there.
@@ -261,6 +275,7 @@ __device__ __forceinline__ uint64_t batch_rows(const ColView& v, uint32_t b) {
 }
 
 __device__ __forceinline__ uint64_t batch_row0(const ColView& v, uint32_t b) {
+  if (v.row0) return v.row0[b];
   return v.units_per_batch ? (uint64_t)b * v.uniform_rows : v.row_start[b];
 }
 

@@ -173,6 +173,10 @@ int build_column_set(olap_ctx* ctx, const void* const* const* cols, int ncols,
   v.units_per_batch = uniform ? (uint32_t)((rows[0] + unit_rows - 1) / unit_rows) : 0;
   v.uniform_rows = uniform ? (uint32_t)rows[0] : 0;
   out->dev_ptr_tables.clear();
+  out->h_ptrs.assign((size_t)ncols, std::vector<const void*>());
+  out->h_rows.assign(rows, rows + nb);
+  out->h_elem.assign(elem_bytes, elem_bytes + ncols);
+  v.row0 = nullptr;
   bool full = nb > 0;
   for (uint64_t b = 0; b < nb; ++b) full = full && rows[b] % unit_rows == 0;
   for (int c = 0; c < ncols; ++c) {
@@ -205,10 +209,93 @@ int build_column_set(olap_ctx* ctx, const void* const* const* cols, int ncols,
       }
     }
     for (uint64_t b = 0; b < nb; ++b) full = full && (((uintptr_t)h_ptrs[b]) & 15) == 0;
+    out->h_ptrs[(size_t)c].assign(h_ptrs, h_ptrs + nb);
     OLAP_HIP(ctx, hipMemcpyAsync(d_ptrs, h_ptrs, (nb ? nb : 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     out->dev_ptr_tables.push_back((const void* const*)d_ptrs);
   }
   out->full_units = full;
+  return OLAP_OK;
+}
+
+uint64_t split_column_set_bytes(uint64_t nb, int ncols) { return 2 * (align_up((nb + 2) * 8, 256) * (3 + (uint64_t)ncols)) + 1024; }
+
+// One derived view: entries (pointers per column, rows, global first row) -> device tables
+static int make_piece_view(olap_ctx* ctx, const std::vector<std::vector<const void*>>& ptrs, const std::vector<uint64_t>& rows,
+                           const std::vector<uint64_t>& row0, uint32_t unit_rows, bool full, ColumnSet* out) {
+  const uint64_t nb = rows.size();
+  const int ncols = (int)ptrs.size();
+  uint64_t* h_unit = (uint64_t*)pinned_alloc(ctx, (nb + 1) * 8);
+  uint64_t* h_row = (uint64_t*)pinned_alloc(ctx, (nb + 1) * 8);
+  uint64_t* h_row0 = (uint64_t*)pinned_alloc(ctx, (nb + 1) * 8);
+  uint64_t* d_unit = (uint64_t*)ws_alloc(ctx, (nb + 1) * 8);
+  uint64_t* d_row = (uint64_t*)ws_alloc(ctx, (nb + 1) * 8);
+  uint64_t* d_row0 = (uint64_t*)ws_alloc(ctx, (nb + 1) * 8);
+  if (!h_unit || !h_row || !h_row0 || !d_unit || !d_row || !d_row0) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (piece views)");
+  h_unit[0] = h_row[0] = 0;
+  for (uint64_t b = 0; b < nb; ++b) {
+    h_row[b + 1] = h_row[b] + rows[b];
+    h_unit[b + 1] = h_unit[b] + (rows[b] + unit_rows - 1) / unit_rows;
+    h_row0[b] = row0[b];
+  }
+  h_row0[nb] = 0;
+  OLAP_HIP(ctx, hipMemcpyAsync(d_unit, h_unit, (nb + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  OLAP_HIP(ctx, hipMemcpyAsync(d_row, h_row, (nb + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  OLAP_HIP(ctx, hipMemcpyAsync(d_row0, h_row0, (nb + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  ColView& v = out->view;
+  v.unit_start = d_unit;
+  v.row_start = d_row;
+  v.row0 = d_row0;
+  v.total_units = h_unit[nb];
+  v.total_rows = h_row[nb];
+  v.nb = (uint32_t)nb;
+  v.unit_rows = unit_rows;
+  bool uniform = nb > 0 && rows[0] > 0 && rows[0] <= 0xFFFFFFFFull;
+  for (uint64_t b = 1; b < nb && uniform; ++b) uniform = rows[b] == rows[0];
+  v.units_per_batch = uniform ? (uint32_t)((rows[0] + unit_rows - 1) / unit_rows) : 0;  // equal pieces: a division instead of a search
+  v.uniform_rows = uniform ? (uint32_t)rows[0] : 0;
+  out->dev_ptr_tables.clear();
+  out->h_ptrs = ptrs;
+  out->h_rows = rows;
+  for (int c = 0; c < ncols; ++c) {
+    const void** h_p = (const void**)pinned_alloc(ctx, (nb ? nb : 1) * 8);
+    const void** d_p = (const void**)ws_alloc(ctx, (nb ? nb : 1) * 8);
+    if (!h_p || !d_p) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (piece views)");
+    for (uint64_t b = 0; b < nb; ++b) h_p[b] = ptrs[(size_t)c][b];
+    OLAP_HIP(ctx, hipMemcpyAsync(d_p, h_p, (nb ? nb : 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    out->dev_ptr_tables.push_back((const void* const*)d_p);
+  }
+  out->full_units = full && nb > 0;
+  return OLAP_OK;
+}
+
+int split_column_set(olap_ctx* ctx, const ColumnSet& cs, ColumnSet* whole, ColumnSet* rest) {
+  const uint64_t nb = cs.h_rows.size();
+  const int ncols = (int)cs.h_ptrs.size();
+  const uint32_t unit = cs.view.unit_rows;
+  std::vector<std::vector<const void*>> pw((size_t)ncols), pr((size_t)ncols);
+  std::vector<uint64_t> rw, rr, zw, zr;
+  uint64_t row0 = 0;
+  for (uint64_t b = 0; b < nb; ++b) {
+    const uint64_t rows = cs.h_rows[b];
+    bool aligned = true;
+    for (int c = 0; c < ncols; ++c) aligned = aligned && (((uintptr_t)cs.h_ptrs[(size_t)c][b]) & 15) == 0;
+    const uint64_t full_rows = aligned ? rows - rows % unit : 0;
+    if (full_rows) {
+      for (int c = 0; c < ncols; ++c) pw[(size_t)c].push_back(cs.h_ptrs[(size_t)c][b]);
+      rw.push_back(full_rows);
+      zw.push_back(row0);
+    }
+    if (rows > full_rows) {
+      for (int c = 0; c < ncols; ++c)
+        pr[(size_t)c].push_back((const char*)cs.h_ptrs[(size_t)c][b] + full_rows * cs.h_elem[(size_t)c]);
+      rr.push_back(rows - full_rows);
+      zr.push_back(row0 + full_rows);
+    }
+    row0 += rows;
+  }
+  OLAP_TRY(make_piece_view(ctx, pw, rw, zw, unit, true, whole));
+  OLAP_TRY(make_piece_view(ctx, pr, rr, zr, unit, false, rest));
+  whole->h_elem = rest->h_elem = cs.h_elem;
   return OLAP_OK;
 }
 

@@ -143,7 +143,9 @@ static uint32_t claim_cap(const olap_ctx* ctx, uint64_t rows, uint64_t F) {
   // allotments a pass-0 workgroup may leave unused per bucket, times the workgroups: one for the write-combining kernel
   // (two workgroups per CU), up to three for the ring scatter (the one in use, the reserve, a claim in flight; one per CU)
   const bool ring = ring_ok(ctx, (uint32_t)ceil_log2_u64(F), 1);
-  const uint64_t kb0 = (uint64_t)ctx->compute_units * (ring ? 3 : 2);
+  // (ring: twice that, because ragged column input is scattered by TWO launches sharing the cursors -- whole aligned
+  // tiles through the straight-line loader, the batches' tails through the generic one)
+  const uint64_t kb0 = (uint64_t)ctx->compute_units * (ring ? 6 : 2);
   const uint64_t kb = kb0 > 256 ? kb0 : 256;
   const uint64_t avg = (rows + F - 1) / F;
   uint64_t sd = 1;
@@ -411,8 +413,31 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
         PhaseScope ps(ctx, PH_PART_SCATTER_CLAIM);
         const ClaimOut co{ccap, cursor, d_overflow, weave ? kWeaveShift : 0u, (uint32_t)(n_seg * F)};
 
-        const int full = cols && cs.full_units && cs.view.unit_rows == ring_tile(ctx) && ctx->ring_full_tiles ? (has_payload ? 1 : 2) : 0;
-        if (ring_claim) OLAP_TRY(launch_ring(ctx, cols, true, (unsigned)blocks, src, shift, fbits, out, CapOut{}, co, full));
+        const bool loader_ok = cols && cs.view.unit_rows == ring_tile(ctx) && ctx->ring_full_tiles && ctx->ring_tpt != 4;
+        const int full = loader_ok && cs.full_units ? (has_payload ? 1 : 2) : 0;
+        if (ring_claim && loader_ok && !cs.full_units && ctx->ring_split_ragged) {
+          // ragged batches (or some unaligned buffers): the whole aligned tiles of every batch through the straight-line
+          // loader, the rest (tails, unaligned batches) through the generic one -- two launches on the same cursors
+          ColumnSet whole, rest;
+          OLAP_TRY(split_column_set(ctx, cs, &whole, &rest));
+          const ColumnSet* parts[2] = {&whole, &rest};
+          for (int k = 0; k < 2; ++k) {
+            const ColumnSet& pc = *parts[k];
+            const uint64_t tiles = pc.view.total_units;
+            if (!tiles) continue;
+            PassSrc s2 = src;
+            s2.v = pc.view;
+            s2.key_ptrs = pc.dev_ptr_tables[0];
+            s2.pay_ptrs = has_payload ? pc.dev_ptr_tables[1] : nullptr;
+            const uint64_t nbk = std::min<uint64_t>((uint64_t)ctx->compute_units, tiles);
+            s2.tiles_per_block = (tiles + nbk - 1) / nbk;
+            // (round-robin tiles only when locating a tile is a division: with pieces of different sizes every tile that does
+            // not follow its predecessor costs a binary search with dependent loads)
+            s2.interleave = k == 0 && pc.view.units_per_batch ? (ctx->ring_interleave >= 0 ? (uint32_t)ctx->ring_interleave : 1u) : 0u;
+            const uint64_t blocks2 = (tiles + s2.tiles_per_block - 1) / s2.tiles_per_block;
+            OLAP_TRY(launch_ring(ctx, true, true, (unsigned)blocks2, s2, shift, fbits, out, CapOut{}, co, k == 0 ? (has_payload ? 1 : 2) : 0));
+          }
+        } else if (ring_claim) OLAP_TRY(launch_ring(ctx, cols, true, (unsigned)blocks, src, shift, fbits, out, CapOut{}, co, full));
         else OLAP_TRY(launch_claim(ctx, cols, g2, (unsigned)blocks, src, shift, fbits, out, co));
         OLAP_HIP(ctx, hipGetLastError());
       }
@@ -556,13 +581,14 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
                   side_scratch_bytes(ctx, NL, lnb, plan, in.l_pre) + side_scratch_bytes(ctx, NR, rnb, plan, in.r_pre) +
                   align_up((lt_tuples + 2) * 8, 256) + align_up((rt_tuples + 2) * 8, 256) + 8192;
   need += align_up((NL / kProbeSlice + 2) * 8, 256) + 256;  // probe slice list
+  need += split_column_set_bytes(lnb, 2) + split_column_set_bytes(rnb, 2);  // piece views of ragged column input
   if (plan.passes >= 2) need += align_up((tmp_tuples + 2) * 8, 256);
   if (plan.passes >= 3) need += align_up((maxN + 2) * 8, 256);
   if (out_mem == OLAP_MEM_HOST) need += 3 * align_up(NL * 4 + 4, 256);
   const bool drop = ctx->join_drop_unmatched != 0;
   const uint64_t miss_words = (NL + 31) / 32 + 2;
   if (drop) need += align_up(miss_words * 4, 256);
-  uint64_t pin = (lnb + rnb + 2) * 8 * 8 + 8192;
+  uint64_t pin = (lnb + rnb + 2) * 8 * 8 + 8192 + split_column_set_pinned(lnb, 2) + split_column_set_pinned(rnb, 2);
   if (in.l_pre) pin += 2 * ((uint64_t)in.l_pre->n_seg * in.l_pre->chunks * 16 + ((uint64_t)in.l_pre->n_seg + 1) * 8 + 512);
   OLAP_TRY(pinned_begin(ctx, pin));
   OLAP_TRY(ws_begin(ctx, need));
@@ -852,6 +878,10 @@ int olap_set_tuning(olap_ctx* ctx, const char* key, int value) {
   if (!std::strcmp(key, "probe_run")) {
     if (value < 1 || value > 65536) return ctx->fail(OLAP_ERR_INVALID, "probe_run must be in [1, 65536]");
     ctx->probe_run = value;
+    return OLAP_OK;
+  }
+  if (!std::strcmp(key, "ring_split_ragged")) {
+    ctx->ring_split_ragged = value != 0;
     return OLAP_OK;
   }
   if (!std::strcmp(key, "ring_full_tiles")) {

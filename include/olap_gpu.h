@@ -299,6 +299,9 @@ int olap_join_configure(olap_ctx* ctx, int radix_bits_total, int max_bits_per_pa
  *                      order (default; only with the automatic radix plan) | 0 always partition
  *   ring_full_tiles    1 column input whose batches are all whole 4096-row tiles in 16-byte aligned buffers is read by a
  *                      loader without the ragged fallback (keeps the prefetch asynchronous; default) | 0 generic loader
+ *   ring_split_ragged  1 pass 0 over ragged batches (or some unaligned buffers) runs as two launches on the same cursors: the
+ *                      whole aligned tiles of every batch through the whole-tile loader, tails and unaligned batches through
+ *                      the generic one (default) | 0 one launch with the generic loader
  *   ring_interleave    -1 automatic (default: pass 0's column tiles are dealt to the workgroups round-robin with the
  *                      whole-tile loader, as contiguous runs otherwise) | 0 contiguous runs | N round-robin in chunks of N tiles
  *   claim_weave        1 the claiming ring scatter weaves its regions in 64 KiB chunks, so that the lines the chip writes at

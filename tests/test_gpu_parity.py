@@ -1302,8 +1302,23 @@ def test_join_ring_scatter_vs_digest(dev, shape, tpt):
     assert dev.get_counter("join_attempts") == 1 and dev.get_counter("join_region_overflows") == 0   # no exact rerun behind the result
     assert not timers.get("partition-hist", 0), timers
     # whole aligned 4096-row tiles are read by the straight-line loader (last template argument 1), anything else by the generic one
+    # (ragged batches: two launches, whole tiles through the straight-line loader and the tails through the generic one, which
+    # is the last one launched)
     claim_kernel = dev.phase_kernel("partition-scatter-claim")
     assert claim_kernel.endswith(", 1>" if (tpt == 8 and shape != "ragged") else ", 0>"), claim_kernel
+    if shape == "ragged" and tpt == 8:   # the same digest with the split off (one launch, generic loader)
+        dev.join_configure(16, 8)
+        dev.set_tuning("claim_mode", 2)
+        dev.set_tuning("ring_split_ragged", 0)
+        try:
+            out0 = o.JoinGpu(dev, [(batch("fk", b), batch("y", b)) for b in range(nb)], [(batch("pk", b), batch("x", b)) for b in range(nb)]).Prepare().Run()
+        finally:
+            dev.join_configure(-1, 0)
+            dev.set_tuning("claim_mode", 1)
+            dev.set_tuning("ring_split_ragged", 1)
+        assert dev.checksum_rows3_u32(out0["fk"].ptr, out0["y"].ptr, out0["x"].ptr, n) == expect
+        for c in out0.values():
+            dev.release(o.DeviceArray(c.ptr, 0))
     ofk = dev.to_host(out["fk"])
     part = oracle.wang_hash_np(ofk) >> np.uint32(16)
     assert (np.diff(part.astype(np.int64)) >= 0).all()
