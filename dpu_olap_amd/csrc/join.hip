@@ -97,7 +97,8 @@ static uint64_t side_scratch_bytes(const olap_ctx* ctx, uint64_t rows, uint64_t 
       blocks = (uint64_t)ctx->compute_units * 2;
       if (blocks > tiles) blocks = tiles;
     } else {
-      blocks = n_seg * seg_blocks(ctx, n_seg);
+      blocks = 2 * n_seg * seg_blocks(ctx, n_seg) + 4 * n_seg + 8;  // (sized segments: an upper bound of the workgroups handed out)
+      bytes += align_up((n_seg + 1) * 4, 256);
     }
     bytes += align_up(blocks * F * 4, 256);          // hist matrix
     bytes += align_up((n_seg * F + 1) * 8, 256);     // segment table
@@ -364,7 +365,7 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
     consumed += fbits;
     const uint32_t shift = 32 - consumed;
     uint2* out = (i == plan.passes - 1) ? final_tuples : ((i & 1) ? tmp1 : tmp0);
-    uint64_t blocks, bseg;
+    uint64_t blocks, bseg, sized_blocks = 0;
     const bool cols = i == 0 && !tuple_in;
     const bool g2 = wc && pass_uses_geometry2(ctx, fbits);  // 512 threads, 4096-tuple tiles, 2 workgroups per CU
     const bool claim_pass = claim && i == 0 && plan.passes == 2 && wc && !pre;  // claiming scatter: no histogram
@@ -394,8 +395,28 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
       }
       src.chunk_split = chunk_split;
       bseg = ranged ? pre->chunks * chunk_split : (capm && i == plan.passes - 1) ? 1 : seg_blocks(ctx, n_seg);
+      // exact passes over the segments of an earlier pass: workgroups per segment in proportion to the segment SIZES
+      // (k_seg_blocks), so that a segment far larger than the others (a hot key) gets its share of the chip -- 2^27 rows with
+      // one key on half of them: pass 1 took 10.4 ms with the same number of workgroups for every segment.  The grid is an
+      // upper bound of what the table hands out.
+      src.blk_first = nullptr;
+      uint32_t* d_blk_first = nullptr;
+      if (!ranged && !(capm && i == plan.passes - 1) && ctx->balance_segments && seg_in && !claim_pass) {
+        const uint64_t tile = g2 ? (uint64_t)kW2Tile : (uint64_t)kPTile;
+        const uint64_t share = std::max<uint64_t>(1, rows / (n_seg * bseg) / tile);  // tiles per workgroup when the segments are equal
+        const uint64_t upper = (rows / tile + 2 * n_seg) / share + n_seg + 1;      // sum of ceil(tiles(seg) / share), tiles(seg) <= rows(seg) / tile + 2
+        if (upper < 0x7FFFFFFFull && share <= 0xFFFFFFFFull) {
+          d_blk_first = (uint32_t*)ws_alloc(ctx, (n_seg + 1) * 4);
+          if (!d_blk_first) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (segment workgroups)");
+          hipLaunchKernelGGL(k_seg_blocks, dim3(1), dim3(1024), 0, ctx->stream, seg_in, (uint32_t)n_seg, (uint32_t)tile, (uint32_t)share,
+                             d_blk_first);
+          OLAP_HIP(ctx, hipGetLastError());
+          src.blk_first = d_blk_first;
+          sized_blocks = upper;
+        }
+      }
       if (ring_claim) bseg = std::max<uint64_t>(1, ((uint64_t)ctx->compute_units + n_seg - 1) / n_seg);  // one workgroup per CU
-      blocks = n_seg * bseg;
+      blocks = src.blk_first ? sized_blocks : n_seg * bseg;
       src.tuples = in_tuples;
       src.seg_off = seg_in;
       src.n_seg = (uint32_t)n_seg;
@@ -488,7 +509,7 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
     {
       PhaseScope ps(ctx, PH_PART_SCAN);
       hipLaunchKernelGGL(k_part_scan, dim3((unsigned)n_seg), dim3(1024), 0, ctx->stream, hist, seg_in, rows,
-                         (uint32_t)n_seg, (uint32_t)bseg, fbits, seg_out);
+                         (uint32_t)n_seg, (uint32_t)bseg, fbits, seg_out, src.blk_first);
       OLAP_HIP(ctx, hipGetLastError());
     }
     {
@@ -865,6 +886,10 @@ int olap_set_tuning(olap_ctx* ctx, const char* key, int value) {
   }
   if (!std::strcmp(key, "filter_whole_batches")) {
     ctx->filter_whole_batches = value < 0 ? 0 : value;  // 0 off, N: from N long batches per CU on
+    return OLAP_OK;
+  }
+  if (!std::strcmp(key, "balance_segments")) {
+    ctx->balance_segments = value != 0;
     return OLAP_OK;
   }
   if (!std::strcmp(key, "probe_slices")) {

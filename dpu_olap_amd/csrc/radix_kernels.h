@@ -44,6 +44,10 @@ struct PassSrc {
   const uint64_t* seg_off;  // [n_seg + 1]
   uint32_t n_seg;
   uint32_t blocks_per_seg;
+  // Workgroups per segment in proportion to the segment SIZES (skew: one segment may hold half of the rows): workgroup k
+  // belongs to the segment seg with blk_first[seg] <= k < blk_first[seg + 1] (k_seg_blocks; [n_seg + 1] on the device);
+  // null: blocks_per_seg workgroups for every segment.
+  const uint32_t* blk_first;
   // SRC_TUPLES, pre-split input: block k of the grid reads tuples [blk_range[2k], blk_range[2k+1])
   // (one chunk per sender of an exchanged segment) instead of an even share of its segment
   const uint64_t* blk_range;
@@ -109,6 +113,28 @@ __device__ __forceinline__ TileRange block_tiles(const PassSrc& s) {
     if (r.t0 > r.t1) r.t0 = r.t1;
     r.lo = r.hi = r.a = 0;
   } else {
+    if (s.blk_first) {  // sized segments
+      uint32_t lo = 0, hi = s.n_seg;  // last seg with blk_first[seg] <= blockIdx.x
+      if (blockIdx.x >= s.blk_first[hi]) {
+        r.seg = 0;
+        r.t0 = r.t1 = r.lo = r.hi = r.a = 0;
+        return r;  // beyond the last segment's workgroups (the grid is an upper bound)
+      }
+      while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (s.blk_first[mid] <= blockIdx.x) lo = mid; else hi = mid;
+      }
+      r.seg = lo;
+      const uint32_t first = s.blk_first[lo], nblk = s.blk_first[lo + 1] - first, j = blockIdx.x - first;
+      r.lo = s.seg_off[r.seg];
+      r.hi = s.seg_off[r.seg + 1];
+      r.a = r.lo & ~1ull;
+      const uint64_t tiles = (r.hi - r.a + TILE - 1) / TILE;
+      const uint64_t q = (tiles + nblk - 1) / nblk;
+      r.t0 = min((uint64_t)j * q, tiles);
+      r.t1 = min(r.t0 + q, tiles);
+      return r;
+    }
     r.seg = blockIdx.x / s.blocks_per_seg;
     if (s.blk_range) {
       const uint32_t split = s.chunk_split ? s.chunk_split : 1u;
@@ -358,9 +384,13 @@ __global__ __launch_bounds__(BLOCK) void k_part_hist(PassSrc s, uint32_t shift, 
   constexpr int TPT = TILE / BLOCK;
   __shared__ uint32_t cl[kMaxF];
   const uint32_t F = 1u << fbits;
+  const TileRange r = block_tiles<SRC, TILE>(s);
+  if (r.t0 >= r.t1) {  // nothing to read: a row of zeros
+    for (uint32_t b = threadIdx.x; b < F; b += BLOCK) hist[(uint64_t)blockIdx.x * F + b] = 0;
+    return;
+  }
   for (uint32_t b = threadIdx.x; b < F; b += BLOCK) cl[b] = 0;
   __syncthreads();
-  const TileRange r = block_tiles<SRC, TILE>(s);
   ColsCursor cur;
   HotGuess hot;
   for (uint64_t tile = r.t0; tile < r.t1; ++tile) {
@@ -378,16 +408,19 @@ __global__ __launch_bounds__(BLOCK) void k_part_hist(PassSrc s, uint32_t shift, 
 // replaced by the exclusive prefix over blk; seg_off_out[seg*F + b] receives the
 // absolute start of output bucket (seg, b) -- the segment table of the next pass.
 __global__ __launch_bounds__(1024) void k_part_scan(uint32_t* hist, const uint64_t* seg_off_in,
-                                                    uint64_t total_in, uint32_t n_seg, uint32_t Bseg,
-                                                    uint32_t fbits, uint64_t* seg_off_out) {
+                                                    uint64_t total_in, uint32_t n_seg, uint32_t Bseg_all,
+                                                    uint32_t fbits, uint64_t* seg_off_out, const uint32_t* blk_first = nullptr) {
   __shared__ uint64_t s_wave[16];
   const uint32_t F = 1u << fbits;
   const uint32_t seg = blockIdx.x;
   const uint32_t b = threadIdx.x;
+  // the segment's workgroups: Bseg_all each, or the sized ranges of k_seg_blocks
+  const uint32_t first_blk = blk_first ? blk_first[seg] : seg * Bseg_all;
+  const uint32_t Bseg = blk_first ? blk_first[seg + 1] - first_blk : Bseg_all;
   uint64_t tot = 0;
   if (b < F) {
     uint32_t run = 0;
-    uint32_t* col = hist + (uint64_t)seg * Bseg * F + b;
+    uint32_t* col = hist + (uint64_t)first_blk * F + b;
     uint32_t blk = 0;
     for (; blk + 4 <= Bseg; blk += 4) {  // 4 independent loads in flight
       const uint32_t c0 = col[(uint64_t)(blk + 0) * F], c1 = col[(uint64_t)(blk + 1) * F];
@@ -419,6 +452,40 @@ __global__ __launch_bounds__(1024) void k_part_scan(uint32_t* hist, const uint64
   if (b < F) seg_off_out[(uint64_t)seg * F + b] = off + incl - tot;
   if (seg == n_seg - 1 && threadIdx.x == 0)
     seg_off_out[(uint64_t)n_seg * F] = seg_off_in ? seg_off_in[n_seg] : total_in;
+}
+
+// Workgroups per segment by size: segment seg gets max(1, ceil(tiles(seg) / share)) of them, share = the tiles a workgroup
+// would take if all segments were equal; blk_first = exclusive prefix ([n_seg + 1]).  One workgroup of 1024 threads.
+__global__ __launch_bounds__(1024) void k_seg_blocks(const uint64_t* seg_off, uint32_t n_seg, uint32_t tile, uint32_t share,
+                                                     uint32_t* blk_first) {
+  __shared__ uint32_t s_wave[16];
+  __shared__ uint32_t s_carry;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < n_seg; base += 1024) {
+    const uint32_t seg = base + threadIdx.x;
+    uint32_t n = 0;
+    if (seg < n_seg) {
+      const uint64_t lo = seg_off[seg], hi = seg_off[seg + 1], a = lo & ~1ull;
+      const uint64_t tiles = (hi - a + tile - 1) / tile;
+      n = (uint32_t)max((uint64_t)1, (tiles + share - 1) / share);
+    }
+    uint32_t incl = n;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+      const uint32_t y = __shfl_up(incl, o, kWave);
+      if ((int)lane_id() >= o) incl += y;
+    }
+    if (lane_id() == kWave - 1) s_wave[threadIdx.x / kWave] = incl;
+    __syncthreads();
+    uint32_t off = s_carry;
+    for (unsigned w = 0; w < threadIdx.x / kWave; ++w) off += s_wave[w];
+    if (seg < n_seg) blk_first[seg] = off + incl - n;
+    __syncthreads();
+    if (threadIdx.x == 1023) s_carry = off + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) blk_first[n_seg] = s_carry;
 }
 
 // --------------------------------------------------------------- scatter
@@ -582,6 +649,7 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_wc(PassSrc s, uint32_t s
   uint64_t* wtot = (uint64_t*)(smem + ((LDS::kWtot + 15) / 16) * 16);  // per-wave (count | flush << 32)
   const uint32_t F = 1u << fbits;
   const TileRange r = block_tiles<SRC, TILE>(s);
+  if (!CAPM && r.t0 >= r.t1) return;  // exact layout: a workgroup without tiles owns no part of the output (uniform)
   const unsigned lane = lane_id();
   const unsigned wave = threadIdx.x / kWave;
   const uint32_t b_own = threadIdx.x;  // BLOCK >= kMaxF: one bucket per thread

@@ -292,6 +292,9 @@ int olap_join_configure(olap_ctx* ctx, int radix_bits_total, int max_bits_per_pa
  *   ring_tpt           8 (default) | 4 tuples per producer thread and tile of the ring scatter
  *   filter_whole_batches N filter: from N batches per CU on (default 2), a batch longer than 64 Ki rows is still walked by ONE
  *                      workgroup (one pass over the data) | 0 always count + scan + compact over 64 Ki-row segments
+ *   balance_segments   1 histogram + scatter passes over the segments of an earlier pass give every segment workgroups in
+ *                      proportion to its size (a table computed on the device): a segment far larger than the rest -- a hot
+ *                      key -- gets its share of the chip (default) | 0 the same number of workgroups for every segment
  *   probe_slices       1 the probe side of a partition is handled in slices of 64 Ki rows, every slice beyond the first a work
  *                      item of its own: a hot foreign key no longer leaves one workgroup with most of the table (default) | 0 off
  *   broadcast_join     1 a right table of <= 6144 rows (one LDS hash table) is joined WITHOUT partitioning: every workgroup
