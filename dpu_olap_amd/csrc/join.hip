@@ -603,6 +603,8 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
                   align_up((lt_tuples + 2) * 8, 256) + align_up((rt_tuples + 2) * 8, 256) + 8192;
   need += align_up((NL / kProbeSlice + 2) * 8, 256) + 256;  // probe slice list
   need += split_column_set_bytes(lnb, 2) + split_column_set_bytes(rnb, 2);  // piece views of ragged column input
+  if (lcap || lclaim) need += side_scratch_bytes(ctx, NL, lnb, plan, in.l_pre);  // an exact redo of a side whose regions overflowed
+  if (rcap || rclaim) need += side_scratch_bytes(ctx, NR, rnb, plan, in.r_pre);
   if (plan.passes >= 2) need += align_up((tmp_tuples + 2) * 8, 256);
   if (plan.passes >= 3) need += align_up((maxN + 2) * 8, 256);
   if (out_mem == OLAP_MEM_HOST) need += 3 * align_up(NL * 4 + 4, 256);
@@ -620,7 +622,7 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
   uint2* tmp1 = plan.passes >= 3 ? (uint2*)ws_alloc(ctx, (maxN + 2) * 8) : nullptr;
   uint2* Lt = (uint2*)ws_alloc(ctx, (lt_tuples + 2) * 8);
   uint2* Rt = (uint2*)ws_alloc(ctx, (rt_tuples + 2) * 8);
-  unsigned long long* d_cnt = (unsigned long long*)ws_alloc(ctx, 48);
+  unsigned long long* d_cnt = (unsigned long long*)ws_alloc(ctx, 64);  // [0..5] probe counters; [4] / [6]: region overflows left / right
   uint32_t *d_fk = out_fk, *d_y = out_y, *d_x = out_x;
   if (out_mem == OLAP_MEM_HOST) {
     d_fk = (uint32_t*)ws_alloc(ctx, NL * 4 + 4);
@@ -629,7 +631,7 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
   }
   if ((plan.passes >= 2 && !tmp0) || (plan.passes >= 3 && !tmp1) || !Lt || !Rt || !d_cnt || !d_fk || !d_y || !d_x)
     return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (join buffers)");
-  OLAP_HIP(ctx, hipMemsetAsync(d_cnt, 0, 48, ctx->stream));
+  OLAP_HIP(ctx, hipMemsetAsync(d_cnt, 0, 64, ctx->stream));
   uint32_t* miss_bits = nullptr;  // inner-join mode: one bit per output row, set where the probe missed
   if (drop) {
     miss_bits = (uint32_t*)ws_alloc(ctx, miss_words * 4);
@@ -662,7 +664,33 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
     OLAP_HIP(ctx, hipStreamWaitEvent(ctx->stream, right_ready, 0));
   }
   OLAP_TRY(partition_side(ctx, rcs, r_pay, in.r_tuples, NR, plan, (uint32_t)ctx->hash_skip_bits, tmp0, tmp1, Rt, rcap,
-                          d_cnt + 4, &rso, in.r_pre, rclaim));
+                          d_cnt + 6, &rso, in.r_pre, rclaim));
+  // The histogram-free layouts (claimed / fixed-capacity regions) overflow when keys repeat far more than the others: a
+  // foreign key with a few hundred rows is enough for its partition's region.  Find out BEFORE the probe, and redo only the
+  // side that overflowed, exactly (histogram + scan + scatter into the same buffer) -- the other side's partitions stay.
+  if (lcap || rcap || lclaim || rclaim) {
+    unsigned long long* h_over = (unsigned long long*)pinned_alloc(ctx, 32);
+    if (!h_over) return ctx->fail(OLAP_ERR_NOMEM, "pinned scratch exhausted");
+    OLAP_HIP(ctx, hipMemcpyAsync(h_over, d_cnt + 4, 24, hipMemcpyDeviceToHost, ctx->stream));
+    OLAP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const unsigned long long over_l = h_over[0], over_r = h_over[2];
+    if (over_l || over_r) {
+      ctx->last_join_region_overflows += over_l + over_r;
+      ++ctx->last_join_attempts;
+      OLAP_HIP(ctx, hipMemsetAsync(d_cnt + 4, 0, 8, ctx->stream));
+      OLAP_HIP(ctx, hipMemsetAsync(d_cnt + 6, 0, 8, ctx->stream));
+      if (over_l) {
+        lso = SideOut{};
+        OLAP_TRY(partition_side(ctx, lcs, l_pay, in.l_tuples, NL, plan, (uint32_t)ctx->hash_skip_bits, tmp0, tmp1, Lt, false, d_cnt + 4, &lso,
+                                in.l_pre, false));
+      }
+      if (over_r) {
+        rso = SideOut{};
+        OLAP_TRY(partition_side(ctx, rcs, r_pay, in.r_tuples, NR, plan, (uint32_t)ctx->hash_skip_bits, tmp0, tmp1, Rt, false, d_cnt + 6, &rso,
+                                in.r_pre, false));
+      }
+    }
+  }
   }
   if (!bc) {
     PhaseScope ps(ctx, PH_JOIN_PROBE);
@@ -827,7 +855,7 @@ static int join_run(olap_ctx* ctx, const JoinIn& jin, uint64_t NL, uint64_t NR, 
     ++ctx->last_join_attempts;
     OLAP_TRY(join_once(ctx, jb, out_fk, out_y, out_x, out_mem, NL, NR, bits, allow_capacity, stats, counters, &kept_rows,
                        attempt == 0 ? right_ready : nullptr));
-    if (attempt == 0) ctx->last_join_region_overflows = counters[4];
+    if (attempt == 0) ctx->last_join_region_overflows += counters[4];  // (join_once handles overflows itself and records them)
     if (counters[4]) {  // a fixed-capacity region overflowed (skew): redo with exact partitioning
       allow_capacity = false;
       continue;

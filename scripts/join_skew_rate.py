@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Joins with a skewed probe side on one MI355X, device-resident: left = 2^27 rows of which a fraction h carries ONE hot
-foreign key (the rest uniform over the 2^24 right keys).  usage: join_skew_rate.py"""
+foreign key (the rest uniform over the right keys).  usage: join_skew_rate.py [log2 left rows = 27] [log2 right rows = 24]"""
 import json
 import os
 import sys
@@ -11,7 +11,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dpu_olap_amd import capi, datagen as dg  # noqa: E402
 
-nl, nr = 1 << 27, 1 << 24
+nl, nr = 1 << (int(sys.argv[1]) if len(sys.argv) > 1 else 27), 1 << (int(sys.argv[2]) if len(sys.argv) > 2 else 24)
 ctx = capi.Context(0)
 br = 1 << 21
 rng = np.random.default_rng(5)
