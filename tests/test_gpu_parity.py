@@ -506,6 +506,11 @@ def test_join_capacity_layout_overflow_falls_back_to_exact(dev):
     out = j.Run()
     assert out["fk"].rows == n
     assert dev.checksum_rows3_u32(out["fk"].ptr, out["y"].ptr, out["x"].ptr, n) == expect
+    # the overflow is found before the probe and only the LEFT side (the skewed one) is redone: one probe launch, and the
+    # histogram ran for one side's passes only
+    t = dev.timers()
+    assert dev.get_counter("join_attempts") == 2 and dev.get_counter("join_region_overflows") > 0
+    assert t["join-probe"]["launches"] == 1 and t["partition-hist"]["launches"] == j.stats["passes"], t
     for c in list(cols.values()) + list(out.values()):
         dev.release(o.DeviceArray(c.ptr, 0))
 
