@@ -199,8 +199,9 @@ struct ColumnSet {
   std::vector<uint32_t> h_elem;
 };
 
-// Two views of the same buffers: `whole` = of every batch whose buffers are 16-byte aligned, the leading whole units
-// (full_units holds), `rest` = everything else (the tails, and unaligned batches entirely).  Both number their rows
+// Two views of the same buffers: `whole` = the whole units of every batch that start at its first 16-byte boundary
+// (full_units holds), `rest` = everything else (the rows in front of that boundary, the tails; batches whose columns are
+// misaligned differently entirely).  Both number their rows
 // globally like `cs` (ColView::row0).  Tables come from the arena / pinned scratch of the current call.
 int split_column_set(olap_ctx* ctx, const ColumnSet& cs, ColumnSet* whole, ColumnSet* rest);
 uint64_t split_column_set_bytes(uint64_t nb, int ncols);

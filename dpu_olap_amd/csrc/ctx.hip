@@ -277,20 +277,23 @@ int split_column_set(olap_ctx* ctx, const ColumnSet& cs, ColumnSet* whole, Colum
   uint64_t row0 = 0;
   for (uint64_t b = 0; b < nb; ++b) {
     const uint64_t rows = cs.h_rows[b];
-    bool aligned = true;
-    for (int c = 0; c < ncols; ++c) aligned = aligned && (((uintptr_t)cs.h_ptrs[(size_t)c][b]) & 15) == 0;
-    const uint64_t full_rows = aligned ? rows - rows % unit : 0;
-    if (full_rows) {
-      for (int c = 0; c < ncols; ++c) pw[(size_t)c].push_back(cs.h_ptrs[(size_t)c][b]);
-      rw.push_back(full_rows);
-      zw.push_back(row0);
-    }
-    if (rows > full_rows) {
-      for (int c = 0; c < ncols; ++c)
-        pr[(size_t)c].push_back((const char*)cs.h_ptrs[(size_t)c][b] + full_rows * cs.h_elem[(size_t)c]);
-      rr.push_back(rows - full_rows);
-      zr.push_back(row0 + full_rows);
-    }
+    // rows in front of the first 16-byte boundary: an Arrow slice moves every column of a batch by the same number of ELEMENTS,
+    // so columns of one element size share it -- those rows go to `rest`, what follows is aligned
+    const uint32_t e0 = cs.h_elem[0];
+    const uint64_t mis = ((uintptr_t)cs.h_ptrs[0][b]) & 15;
+    bool same = mis % e0 == 0;
+    for (int c = 1; c < ncols; ++c) same = same && cs.h_elem[(size_t)c] == e0 && (((uintptr_t)cs.h_ptrs[(size_t)c][b]) & 15) == mis;
+    const uint64_t head = same ? std::min<uint64_t>(rows, ((16 - mis) & 15) / e0) : rows;  // (different misalignments: all of it to `rest`)
+    const uint64_t full_rows = (rows - head) - (rows - head) % unit;
+    auto piece = [&](std::vector<std::vector<const void*>>& pp, std::vector<uint64_t>& rws, std::vector<uint64_t>& zs, uint64_t first, uint64_t n) {
+      if (!n) return;
+      for (int c = 0; c < ncols; ++c) pp[(size_t)c].push_back((const char*)cs.h_ptrs[(size_t)c][b] + first * cs.h_elem[(size_t)c]);
+      rws.push_back(n);
+      zs.push_back(row0 + first);
+    };
+    piece(pr, rr, zr, 0, head);
+    piece(pw, rw, zw, head, full_rows);
+    piece(pr, rr, zr, head + full_rows, rows - head - full_rows);
     row0 += rows;
   }
   OLAP_TRY(make_piece_view(ctx, pw, rw, zw, unit, true, whole));

@@ -12,7 +12,9 @@ from dpu_olap_amd import capi, datagen as dg  # noqa: E402
 nb, rows = 1024, (2 << 20) - 1234
 n = nb * rows
 ctx = capi.Context(0)
-stride = (rows * 4 + 15) // 16 * 16       # every batch starts 16-byte aligned (its own Arrow buffer), its length is ragged
+# default: every batch starts 16-byte aligned (its own Arrow buffer), its length is ragged; "unaligned": the batches follow each other
+# without padding (slices of one buffer): every other one starts 8 bytes off a 16-byte boundary
+stride = rows * 4 if "unaligned" in sys.argv else (rows * 4 + 15) // 16 * 16
 fk, y, pk, x = (ctx.malloc(nb * stride + 64) for _ in range(4))
 out = [ctx.malloc(n * 4) for _ in range(3)]
 m = nb * stride // 4                       # the padding words between batches are generated too and simply not part of any batch
