@@ -368,7 +368,20 @@ __global__ __launch_bounds__(kTBlock, 4) void k_take_lds(ColView dv, ColView iv,
 #pragma unroll
         for (int j = 0; j < kTWindowBytes / 16 / kTBlock; ++j) ((uint4*)s_win)[j * kTBlock + threadIdx.x] = gload4(src + j * kTBlock + threadIdx.x);
       } else {
-        for (uint32_t i = threadIdx.x; i < wn; i += kTBlock) win[i] = gload_t(data + w0 + i);
+        // a partial window, or a buffer that is only element-aligned (an Arrow slice): 16-byte loads over the aligned
+        // middle (stored element by element: the LDS side is then not 16-byte aligned), scalars at both ends
+        constexpr uint32_t E = 16 / sizeof(T);
+        const T* src = data + w0;
+        const uint32_t head = min(wn, (uint32_t)(((16 - (((uintptr_t)src) & 15)) & 15) / sizeof(T)));
+        const uint32_t nvec = (wn - head) / E;
+        for (uint32_t i = threadIdx.x; i < head; i += kTBlock) win[i] = gload_t(src + i);
+        const typename Vec16<T>::type* sv = (const typename Vec16<T>::type*)(src + head);
+        for (uint32_t i = threadIdx.x; i < nvec; i += kTBlock) {
+          const typename Vec16<T>::type v = gload_vec16(sv + i);
+#pragma unroll
+          for (uint32_t k = 0; k < E; ++k) win[head + i * E + k] = vec_get<T>(v, (int)k);
+        }
+        for (uint32_t i = head + nvec * E + threadIdx.x; i < wn; i += kTBlock) win[i] = gload_t(src + i);
       }
       __syncthreads();
 #pragma unroll
