@@ -163,13 +163,15 @@ __global__ __launch_bounds__(kBlock) void k_filter_count(ColView sv, const void*
     const uint64_t r0 = l.local_unit * sv.unit_rows;
     const uint32_t n_seg = (uint32_t)min((uint64_t)sv.unit_rows, rows - r0);
     const T* in = (const T*)in_ptrs[l.batch] + r0;
-    const bool aligned = (((uintptr_t)in) & 15) == 0;
+    // a buffer that is only element-aligned (an Arrow slice): a short first tile up to the first 16-byte boundary,
+    // whole aligned tiles after it
+    const uint32_t head = min(n_seg, (uint32_t)(((16 - (((uintptr_t)in) & 15)) & 15) / sizeof(T)));
     uint32_t cnt = 0;
-    for (uint32_t t0 = 0; t0 < n_seg; t0 += TILE) {
-      const uint32_t n = min(TILE, n_seg - t0);
+    for (uint32_t t0 = 0, step = head ? head : TILE; t0 < n_seg; t0 += step, step = TILE) {
+      const uint32_t n = min(step, n_seg - t0);
       T val[kVecPerThread][E];
       uint32_t flags[kVecPerThread];
-      filter_tile_flags<T>(in + t0, n, TILE, aligned && n == TILE, thr, val, flags);
+      filter_tile_flags<T>(in + t0, n, TILE, n == TILE, thr, val, flags);
 #pragma unroll
       for (int j = 0; j < kVecPerThread; ++j) cnt += __popc(flags[j]);
     }
@@ -237,13 +239,13 @@ __global__ __launch_bounds__(kBlock) void k_filter_compact(ColView sv, const voi
     const uint32_t n_seg = (uint32_t)min((uint64_t)sv.unit_rows, rows - r0);
     const T* in = (const T*)in_ptrs[l.batch] + r0;
     T* out = (T*)out_ptrs[l.batch];
-    const bool aligned = (((uintptr_t)in) & 15) == 0;
+    const uint32_t head = min(n_seg, (uint32_t)(((16 - (((uintptr_t)in) & 15)) & 15) / sizeof(T)));  // (as in k_filter_count)
     uint64_t base = seg_base ? seg_base[seg] : 0;
-    for (uint32_t t0 = 0; t0 < n_seg; t0 += TILE) {
-      const uint32_t n = min(TILE, n_seg - t0);
+    for (uint32_t t0 = 0, step = head ? head : TILE; t0 < n_seg; t0 += step, step = TILE) {
+      const uint32_t n = min(step, n_seg - t0);
       T val[kVecPerThread][E];
       uint32_t flags[kVecPerThread];
-      filter_tile_flags<T>(in + t0, n, TILE, aligned && n == TILE, thr, val, flags);
+      filter_tile_flags<T>(in + t0, n, TILE, n == TILE, thr, val, flags);
       uint32_t rank[kVecPerThread];
 #pragma unroll
       for (int j = 0; j < kVecPerThread; ++j) {
