@@ -100,6 +100,9 @@ struct olap_ctx {
   int ring_full_tiles = 1; // ring scatter from columns: the straight-line loader when all batches are whole aligned tiles
   int claim_weave = 1;     // claiming ring scatter writes woven regions (radix_kernels.h woven_at)
   int ring_interleave = -1; // ring scatter from columns: tiles dealt to the workgroups round-robin in chunks of this many (0: one contiguous run each; -1: automatic)
+  int pack6 = 1;           // the last (capacity, ring) pass hands the direct-table probe 6-byte tuples {payload, low 16 hash bits} (pack6.h)
+  int ring6_tpt = 8;       // packed last pass: tuples per producer thread and tile
+  int probe6_geometry = 0; // packed probe: 0 two workgroups of 512 per CU, 1 one workgroup of 1024
   int ring_tpt = 8;        // tuples per producer thread and tile of the ring scatter (8: 4096-tuple tiles, 4: 2048)
   int claim_mode = 1;      // pass 0 of a two-pass plan without histogram (claimed allotments): 0 off, 1 auto, 2 always
   int hash_skip_bits = 0;  // top hash bits already fixed by an upstream owner split

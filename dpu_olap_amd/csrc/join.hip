@@ -18,6 +18,7 @@
 #include "probe_kernels.h"
 #include "radix_kernels.h"
 #include "ring_scatter.h"
+#include "pack6.h"
 #include "radix64.h"
 
 namespace olap {
@@ -104,7 +105,7 @@ static uint64_t side_scratch_bytes(const olap_ctx* ctx, uint64_t rows, uint64_t 
     bytes += align_up((n_seg * F + 1) * 8, 256);     // segment table
     n_seg *= F;
   }
-  bytes += align_up(n_seg * 4, 256) + align_up(n_seg * 8, 256);  // capacity-layout tables
+  bytes += 2 * align_up(n_seg * 4, 256) + align_up(n_seg * 8, 256);  // capacity-layout tables (+ the packed layout's hash bits)
   bytes += align_up((1ull << plan.bits[0]) * 4, 256) + align_up((1ull << plan.bits[0]) * 8, 256);  // claim cursors, segment totals
   return bytes + 4096;
 }
@@ -115,6 +116,8 @@ struct SideOut {
   uint32_t cap = 0;          // capacity layout: tuples per region (0 = exact)
   uint32_t* cnt = nullptr;   // capacity layout: [P]
   uint64_t* dense = nullptr; // capacity layout: [P]
+  bool packed = false;       // capacity layout of 6-byte tuples (pack6.h)
+  uint32_t* top = nullptr;   // packed: [P] hash bits above the table bits
 };
 
 // Region size of the capacity layout: the average partition plus the larger of 1/8 and six standard deviations of a
@@ -126,6 +129,12 @@ static uint32_t region_cap(uint64_t rows, uint64_t P) {
   while (sd * sd < 2 * avg) ++sd;
   const uint64_t slack = avg / 8 > 6 * sd ? avg / 8 : 6 * sd;
   return (uint32_t)align_up(avg + slack + 64, kLineAlign);
+}
+
+// ... of a side the last pass writes as 6-byte tuples (pack6.h): whole 128-byte lines per region
+static uint32_t region_cap_side(uint64_t rows, uint64_t P, bool packed) {
+  const uint32_t cap = region_cap(rows, P);
+  return packed ? (uint32_t)align_up(cap, kPackAlign) : cap;
 }
 
 // The last pass may skip its histogram (capacity layout) when every workgroup owns whole
@@ -277,6 +286,32 @@ static int launch_ring(olap_ctx* ctx, bool cols, bool claim, unsigned blocks, co
             : launch_ring_as<SRC_TUPLES, false, 8>(ctx, blocks, src, shift, fbits, out, co, cq);
 }
 
+// capacity-layout ring scatter with 6-byte output tuples (pack6.h)
+template <int TPT>
+static int launch_ring6_as(olap_ctx* ctx, unsigned blocks, const PassSrc& src, uint32_t shift, uint32_t fbits, void* out, const CapOut& co,
+                           uint32_t* ptop, unsigned long long* foreign) {
+  constexpr uint32_t kLds = Ring6Cfg<kRingFmax, kRingBlock, kRingProd>::kBytes;
+  auto kernel = k_part_scatter_ring6<kRingFmax, kRingBlock, kRingProd, TPT>;
+  OLAP_TRY(allow_lds(ctx, reinterpret_cast<const void*>(kernel), kLds));
+  char label[96];
+  std::snprintf(label, sizeof label, "olap::k_part_scatter_ring6<%d, %d, %d, %d>", kRingFmax, kRingBlock, kRingProd, TPT);
+  ctx->phase_kernel[PH_PART_SCATTER_CAP] = label;
+  hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kRingBlock), kLds, ctx->stream, src, shift, fbits, (uint16_t*)out, co, ptop, foreign);
+  OLAP_HIP(ctx, hipGetLastError());
+  return OLAP_OK;
+}
+static int launch_ring6(olap_ctx* ctx, unsigned blocks, const PassSrc& src, uint32_t shift, uint32_t fbits, void* out, const CapOut& co,
+                        uint32_t* ptop, unsigned long long* foreign) {
+  return ctx->ring6_tpt == 4 ? launch_ring6_as<4>(ctx, blocks, src, shift, fbits, out, co, ptop, foreign)
+                             : launch_ring6_as<8>(ctx, blocks, src, shift, fbits, out, co, ptop, foreign);
+}
+
+// The last pass of a side may hand the probe 6-byte tuples: capacity layout through the ring scatter, direct-address table.
+static bool pack6_ok(const olap_ctx* ctx, const PassPlan& plan, uint32_t table_bits, bool direct) {
+  return ctx->pack6 && direct && plan.passes >= 2 && table_bits >= 1 && table_bits <= 16 &&
+         ring_ok(ctx, plan.bits[plan.passes - 1], 2);
+}
+
 // tile-staged scatter without residues (scatter_variant = 1, A/B)
 static int launch_staged(olap_ctx* ctx, bool cols, unsigned blocks, const PassSrc& src, uint32_t shift, uint32_t fbits, const uint32_t* hist,
                          const uint64_t* seg_out, uint2* out) {
@@ -303,7 +338,8 @@ static void launch_hist(olap_ctx* ctx, bool cols, bool g2, unsigned blocks, cons
 static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, const uint2* tuple_in,
                           uint64_t tuple_n, const PassPlan& plan, uint32_t skip_bits, uint2* tmp0, uint2* tmp1,
                           uint2* final_tuples, bool capm, unsigned long long* d_overflow, SideOut* so,
-                          const Presplit* pre = nullptr, bool claim = false, const BucketOrder* order = nullptr) {
+                          const Presplit* pre = nullptr, bool claim = false, const BucketOrder* order = nullptr, bool pack = false,
+                          unsigned long long* d_foreign = nullptr) {
   const uint64_t rows = tuple_in ? tuple_n : cs.view.total_rows;
   PassSrc src{};
   uint64_t n_seg = 1;
@@ -475,7 +511,13 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
       continue;
     }
     if (capm && i == plan.passes - 1 && !src.blk_range) {  // capacity layout: scatter only
-      so->cap = region_cap(rows, n_seg * F);
+      const bool pack6 = pack && ring_cap;
+      so->cap = region_cap_side(rows, n_seg * F, pack6);
+      so->packed = pack6;
+      if (pack6) {
+        so->top = (uint32_t*)ws_alloc(ctx, n_seg * F * 4);
+        if (!so->top || !d_foreign) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (partition hash bits)");
+      }
       so->cnt = (uint32_t*)ws_alloc(ctx, n_seg * F * 4);
       so->dense = (uint64_t*)ws_alloc(ctx, n_seg * F * 8);
       if (!so->cnt || !so->dense) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (capacity tables)");
@@ -486,7 +528,8 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
         if (!seg_total) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (segment totals)");
       }
       CapOut co{so->cap, so->cnt, so->dense, d_overflow, seg_total};
-      if (ring_cap) OLAP_TRY(launch_ring(ctx, /*cols=*/false, false, (unsigned)blocks, src, shift, fbits, out, co, ClaimOut{}));
+      if (pack6) OLAP_TRY(launch_ring6(ctx, (unsigned)blocks, src, shift, fbits, out, co, so->top, d_foreign));
+      else if (ring_cap) OLAP_TRY(launch_ring(ctx, /*cols=*/false, false, (unsigned)blocks, src, shift, fbits, out, co, ClaimOut{}));
       else OLAP_TRY((launch_scatter<true>(ctx, /*cols=*/false, g2, fbits <= 9 && ctx->line16, (unsigned)blocks, src, shift, fbits, nullptr,
                                           nullptr, out, co)));
       OLAP_HIP(ctx, hipGetLastError());
@@ -557,6 +600,41 @@ struct JoinIn {
   bool broadcast = false;           // the right table fits one LDS table: no partitioning (k_join_broadcast)
 };
 
+// direct-table probe over packed partitions (pack6.h).  probe6_geometry: 0 = two workgroups of 512 per CU (256-tuple
+// chunks per wave), 1 = one workgroup of 1024 per CU (512-tuple chunks).
+template <int BLOCK, int CHUNK>
+static int launch_probe6_as(olap_ctx* ctx, bool rpk, bool lpk, const PartView& rv, const PartView& lv, uint32_t P, uint32_t table_bits,
+                            uint32_t* d_fk, uint32_t* d_y, uint32_t* d_x, uint32_t pair_ok, unsigned long long* d_cnt, uint32_t* miss_bits,
+                            const ProbeSlices& slices) {
+  constexpr uint32_t kLds = kDSlots * 4 + kDSlots / 8 + (BLOCK / kWave) * CHUNK * 6;
+  uint64_t grid = (uint64_t)ctx->compute_units * (BLOCK == 512 ? 8 : 4);
+  if (grid > P) grid = P;
+  char label[96];
+  std::snprintf(label, sizeof label, "olap::k_join_probe_direct6<%d, %d, %s, %s>", BLOCK, CHUNK, rpk ? "true" : "false", lpk ? "true" : "false");
+  ctx->phase_kernel[PH_JOIN_PROBE] = label;
+#define OLAP_PROBE6(RPK, LPK)                                                                                                      \
+  do {                                                                                                                             \
+    auto kernel = k_join_probe_direct6<BLOCK, CHUNK, RPK, LPK>;                                                                    \
+    OLAP_TRY(allow_lds(ctx, reinterpret_cast<const void*>(kernel), kLds));                                                         \
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(BLOCK), kLds, ctx->stream, rv, lv, P, table_bits, d_fk, d_y, d_x, pair_ok, \
+                       d_cnt, miss_bits, slices);                                                                                  \
+  } while (0)
+  if (rpk && lpk) OLAP_PROBE6(true, true);
+  else if (rpk) OLAP_PROBE6(true, false);
+  else OLAP_PROBE6(false, true);
+#undef OLAP_PROBE6
+  OLAP_HIP(ctx, hipGetLastError());
+  return OLAP_OK;
+}
+
+static int launch_probe6(olap_ctx* ctx, bool rpk, bool lpk, const PartView& rv, const PartView& lv, uint32_t P, uint32_t table_bits,
+                         uint32_t* d_fk, uint32_t* d_y, uint32_t* d_x, uint32_t pair_ok, unsigned long long* d_cnt, uint32_t* miss_bits,
+                         const ProbeSlices& slices) {
+  if (ctx->probe6_geometry == 1)
+    return launch_probe6_as<1024, 512>(ctx, rpk, lpk, rv, lv, P, table_bits, d_fk, d_y, d_x, pair_ok, d_cnt, miss_bits, slices);
+  return launch_probe6_as<512, 256>(ctx, rpk, lpk, rv, lv, P, table_bits, d_fk, d_y, d_x, pair_ok, d_cnt, miss_bits, slices);
+}
+
 static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t* out_y, uint32_t* out_x, int out_mem,
                      uint64_t NL, uint64_t NR, uint32_t total_bits, bool allow_capacity, olap_join_stats* st,
                      unsigned long long counters[6], uint64_t* rows_out, hipEvent_t right_ready) {
@@ -590,8 +668,20 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
   const uint64_t maxN = NL > NR ? NL : NR;
   const bool lcap = allow_capacity && capacity_eligible(ctx, NL, plan, pre_bits);
   const bool rcap = allow_capacity && capacity_eligible(ctx, NR, plan, pre_bits);
-  const uint64_t lt_tuples = bc ? 0 : lcap ? (uint64_t)P * region_cap(NL, P) : NL;
-  const uint64_t rt_tuples = bc ? 0 : rcap ? (uint64_t)P * region_cap(NR, P) : NR;
+  // 6-byte tuples from the last pass to the probe (pack6.h); a side that is redone exactly falls back to 8-byte tuples
+  const bool pk_ok = !bc && pack6_ok(ctx, plan, table_bits, direct);
+  const bool lpack = pk_ok && lcap, rpack = pk_ok && rcap;
+  // final buffers in 8-byte units: the (possibly packed) capacity layout, and never less than an exact redo of the side needs
+  auto final_units = [&](uint64_t rows, bool cap, bool pack) -> uint64_t {
+    if (bc) return 0;
+    if (!cap) return rows;
+    const uint64_t regions = (uint64_t)P * region_cap_side(rows, P, pack);
+    return pack ? std::max<uint64_t>((regions * 6 + 7) / 8 + 512, rows) : regions;  // (+ 4 KiB: the probe's chunks read whole vectors)
+  };
+  const uint64_t lt_tuples = final_units(NL, lcap, lpack);
+  const uint64_t rt_tuples = final_units(NR, rcap, rpack);
+  if (lpack && (uint64_t)P * region_cap_side(NL, P, true) * 3 / 64 >= (1ull << 32)) return ctx->fail(OLAP_ERR_INVALID, "packed layout: too many lines");
+  if (rpack && (uint64_t)P * region_cap_side(NR, P, true) * 3 / 64 >= (1ull << 32)) return ctx->fail(OLAP_ERR_INVALID, "packed layout: too many lines");
   const bool lclaim = !in.l_pre && claim_eligible(ctx, NL, plan, lcap);
   const bool rclaim = !in.r_pre && claim_eligible(ctx, NR, plan, rcap);
   uint64_t tmp_tuples = maxN;  // pass-0 output: dense, or the claiming scatter's padded regions
@@ -622,7 +712,9 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
   uint2* tmp1 = plan.passes >= 3 ? (uint2*)ws_alloc(ctx, (maxN + 2) * 8) : nullptr;
   uint2* Lt = (uint2*)ws_alloc(ctx, (lt_tuples + 2) * 8);
   uint2* Rt = (uint2*)ws_alloc(ctx, (rt_tuples + 2) * 8);
-  unsigned long long* d_cnt = (unsigned long long*)ws_alloc(ctx, 64);  // [0..5] probe counters; [4] / [6]: region overflows left / right
+  // [0..5] probe counters; [4] / [6]: region overflows left / right; [8] / [9]: tuples of the left / right side that the
+  // packed last pass found outside their segment's leading hash bits (added to [5] on the host)
+  unsigned long long* d_cnt = (unsigned long long*)ws_alloc(ctx, 128);
   uint32_t *d_fk = out_fk, *d_y = out_y, *d_x = out_x;
   if (out_mem == OLAP_MEM_HOST) {
     d_fk = (uint32_t*)ws_alloc(ctx, NL * 4 + 4);
@@ -631,7 +723,7 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
   }
   if ((plan.passes >= 2 && !tmp0) || (plan.passes >= 3 && !tmp1) || !Lt || !Rt || !d_cnt || !d_fk || !d_y || !d_x)
     return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (join buffers)");
-  OLAP_HIP(ctx, hipMemsetAsync(d_cnt, 0, 64, ctx->stream));
+  OLAP_HIP(ctx, hipMemsetAsync(d_cnt, 0, 128, ctx->stream));
   uint32_t* miss_bits = nullptr;  // inner-join mode: one bit per output row, set where the probe missed
   if (drop) {
     miss_bits = (uint32_t*)ws_alloc(ctx, miss_words * 4);
@@ -659,12 +751,12 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
     OLAP_HIP(ctx, hipGetLastError());
   } else {
   OLAP_TRY(partition_side(ctx, lcs, l_pay, in.l_tuples, NL, plan, (uint32_t)ctx->hash_skip_bits, tmp0, tmp1, Lt, lcap,
-                          d_cnt + 4, &lso, in.l_pre, lclaim));
+                          d_cnt + 4, &lso, in.l_pre, lclaim, nullptr, lpack, d_cnt + 8));
   if (right_ready) {  // the right table may still be arriving (olap_join_set_right_ready_event)
     OLAP_HIP(ctx, hipStreamWaitEvent(ctx->stream, right_ready, 0));
   }
   OLAP_TRY(partition_side(ctx, rcs, r_pay, in.r_tuples, NR, plan, (uint32_t)ctx->hash_skip_bits, tmp0, tmp1, Rt, rcap,
-                          d_cnt + 6, &rso, in.r_pre, rclaim));
+                          d_cnt + 6, &rso, in.r_pre, rclaim, nullptr, rpack, d_cnt + 9));
   // The histogram-free layouts (claimed / fixed-capacity regions) overflow when keys repeat far more than the others: a
   // foreign key with a few hundred rows is enough for its partition's region.  Find out BEFORE the probe, and redo only the
   // side that overflowed, exactly (histogram + scan + scatter into the same buffer) -- the other side's partitions stay.
@@ -681,11 +773,13 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
       OLAP_HIP(ctx, hipMemsetAsync(d_cnt + 6, 0, 8, ctx->stream));
       if (over_l) {
         lso = SideOut{};
+        OLAP_HIP(ctx, hipMemsetAsync(d_cnt + 8, 0, 8, ctx->stream));  // (what an overflowing attempt read may be stale memory)
         OLAP_TRY(partition_side(ctx, lcs, l_pay, in.l_tuples, NL, plan, (uint32_t)ctx->hash_skip_bits, tmp0, tmp1, Lt, false, d_cnt + 4, &lso,
                                 in.l_pre, false));
       }
       if (over_r) {
         rso = SideOut{};
+        OLAP_HIP(ctx, hipMemsetAsync(d_cnt + 9, 0, 8, ctx->stream));
         OLAP_TRY(partition_side(ctx, rcs, r_pay, in.r_tuples, NR, plan, (uint32_t)ctx->hash_skip_bits, tmp0, tmp1, Rt, false, d_cnt + 6, &rso,
                                 in.r_pre, false));
       }
@@ -696,8 +790,8 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
     PhaseScope ps(ctx, PH_JOIN_PROBE);
     uint64_t grid = (uint64_t)ctx->compute_units * 8;
     if (grid > P) grid = P;
-    const PartView rv{Rt, rso.off, rso.cnt, rso.dense, rso.cap};
-    const PartView lv{Lt, lso.off, lso.cnt, lso.dense, lso.cap};
+    const PartView rv{Rt, rso.off, rso.cnt, rso.dense, rso.cap, rso.top};
+    const PartView lv{Lt, lso.off, lso.cnt, lso.dense, lso.cap, lso.top};
     const uintptr_t a_fk = (uintptr_t)d_fk & 7, a_y = (uintptr_t)d_y & 7, a_x = (uintptr_t)d_x & 7;
     const uint32_t pair_ok = (a_fk | a_y | a_x) == 0 ? 1u : (a_fk == 4 && a_y == 4 && a_x == 4) ? 2u : 0u;
     ctx->phase_kernel[PH_JOIN_PROBE] = direct ? "olap::k_join_probe_direct" : "olap::k_join_probe";
@@ -711,7 +805,9 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
       OLAP_HIP(ctx, hipMemsetAsync(slices.count, 0, 16, ctx->stream));
       hipLaunchKernelGGL(k_probe_slices, dim3((P + 255) / 256), dim3(256), 0, ctx->stream, lv, P, slices);
     }
-    if (direct) {
+    if (direct && (rso.packed || lso.packed)) {
+      OLAP_TRY(launch_probe6(ctx, rso.packed, lso.packed, rv, lv, P, table_bits, d_fk, d_y, d_x, pair_ok, d_cnt, miss_bits, slices));
+    } else if (direct) {
       uint64_t dgrid = (uint64_t)ctx->compute_units * 8;
       if (dgrid > P) dgrid = P;
       const uint32_t run = (uint32_t)std::max(1, ctx->probe_run);
@@ -723,8 +819,12 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
     }
     OLAP_HIP(ctx, hipGetLastError());
   }
+  unsigned long long* h_foreign = (unsigned long long*)pinned_alloc(ctx, 16);
+  if (!h_foreign) return ctx->fail(OLAP_ERR_NOMEM, "pinned scratch exhausted");
   OLAP_HIP(ctx, hipMemcpyAsync(counters, d_cnt, 48, hipMemcpyDeviceToHost, ctx->stream));
+  OLAP_HIP(ctx, hipMemcpyAsync(h_foreign, d_cnt + 8, 16, hipMemcpyDeviceToHost, ctx->stream));
   OLAP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  counters[5] += h_foreign[0] + h_foreign[1];
   if (counters[5] && counters[2] == 0 && counters[4] == 0)
     return ctx->fail(OLAP_ERR_INVALID, "%llu tuple(s) do not share the %d leading hash bits this join was told are fixed "
                      "(olap_join_set_hash_skip_bits): the inputs were not split by owner", counters[5], ctx->hash_skip_bits);
@@ -948,6 +1048,20 @@ int olap_set_tuning(olap_ctx* ctx, const char* key, int value) {
   if (!std::strcmp(key, "ring_interleave")) {
     if (value < -1 || value > 4096) return ctx->fail(OLAP_ERR_INVALID, "ring_interleave must be in [-1, 4096]");
     ctx->ring_interleave = value;
+    return OLAP_OK;
+  }
+  if (!std::strcmp(key, "pack6")) {
+    ctx->pack6 = value != 0;
+    return OLAP_OK;
+  }
+  if (!std::strcmp(key, "ring6_tpt")) {
+    if (value != 4 && value != 8) return ctx->fail(OLAP_ERR_INVALID, "ring6_tpt must be 4 or 8");
+    ctx->ring6_tpt = value;
+    return OLAP_OK;
+  }
+  if (!std::strcmp(key, "probe6_geometry")) {
+    if (value < 0 || value > 1) return ctx->fail(OLAP_ERR_INVALID, "probe6_geometry must be 0 (2 x 512 threads per CU) or 1 (1 x 1024)");
+    ctx->probe6_geometry = value;
     return OLAP_OK;
   }
   if (!std::strcmp(key, "ring_tpt")) {
@@ -1212,3 +1326,13 @@ int olap_split_tuples_u32(olap_ctx* ctx, const uint32_t* const* key_ptrs, const 
 }  // extern "C"
 
 #include "join64.h"
+
+#ifdef OLAP_EXP_PHASE_CLOCKS
+// experiment builds only (not part of include/olap_gpu.h): reads and clears the ring scatter's phase clocks
+extern "C" int olap_debug_ring_clocks(unsigned long long* out32) {
+  if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(olap::g_ring_clk), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
+  unsigned long long zero[32] = {0};
+  if (hipMemcpyToSymbol(HIP_SYMBOL(olap::g_ring_clk), zero, sizeof zero) != hipSuccess) return -1;
+  return 0;
+}
+#endif

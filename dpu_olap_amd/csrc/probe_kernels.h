@@ -21,6 +21,7 @@ struct PartView {
   const uint32_t* cnt;
   const uint64_t* dense;
   uint32_t cap;
+  const uint32_t* top;  // packed side (pack6.h: t = 6-byte tuples, capacity layout): per partition, the hash bits above the table bits
 };
 
 // A probe partition far larger than the others (one hot foreign key) would be streamed by ONE workgroup while the rest of

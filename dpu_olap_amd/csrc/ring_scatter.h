@@ -35,6 +35,19 @@ namespace olap {
 
 constexpr uint32_t kRingNone = 0xFFFFFFFFu;
 
+#ifdef OLAP_EXP_PHASE_CLOCKS
+// Timing experiment (scripts/build_variant.sh + scripts/exp_join_timing.py --clocks): shader-clock sums of the ring scatter's
+// phases, taken by one producer wave and one flusher wave of every 16th workgroup.
+// [role 0 claim / 1 capacity][0] producer: insert, [1] producer: wait at barrier 1, [2] producer: hash + loads, [3] producer: wait at
+// barrier 2, [4] flusher: wait at barrier 1, [5] flusher: flush, [6] flusher: wait at barrier 2, [7] tiles counted
+__device__ unsigned long long g_ring_clk[2][16];  // ... [8] producer: wait for tile + 1, [9] hash, [10] claims, [11] load issue; [12] flusher: line rounds, [13] owner update
+#define OLAP_CLK(var) const unsigned long long var = __builtin_readcyclecounter()
+#define OLAP_CLK_ADD(role, slot, val) do { if (clk_on) atomicAdd(&g_ring_clk[role][slot], (unsigned long long)(val)); } while (0)
+#else
+#define OLAP_CLK(var) do {} while (0)
+#define OLAP_CLK_ADD(role, slot, val) do {} while (0)
+#endif
+
 template <int FMAX, int LINE, int BLOCK, int NPROD>
 struct RingCfg {
   static constexpr int kRingMin = 2 * LINE;        // tuples per bucket ring at FMAX buckets; F buckets: FMAX * kRingMin / F
@@ -128,7 +141,11 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring(PassSrc s, uint32_t
     r.t0 = 0;
     r.t1 = chunks > blockIdx.x ? (chunks - blockIdx.x + gridDim.x - 1) / gridDim.x * il_n : 0;
   }
+#ifdef OLAP_EXP_NOLOAD  // timing experiment: every workgroup re-reads its first four tiles (cache resident)
+  auto tile_at = [&](uint64_t i) { return il ? (((i & 3) / il_n) * gridDim.x + blockIdx.x) * il_n + (i & 3) % il_n : r.t0 + ((i - r.t0) & 3); };
+#else
   auto tile_at = [&](uint64_t i) { return il ? ((i / il_n) * gridDim.x + blockIdx.x) * il_n + i % il_n : i; };
+#endif
   auto tile_ok = [&](uint64_t i) { return i < r.t1 && (!il || tile_at(i) < il_total); };
   if (CLAIM && r.t0 >= r.t1) return;  // nothing to read: claim nothing (uniform)
   const unsigned lane = lane_id();
@@ -174,7 +191,11 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring(PassSrc s, uint32_t
     const uint32_t tb = threadIdx.x;
     uint32_t claimed = 0;   // the atomic's answer, in flight until the next tile's loads have been awaited
     bool pending = false;
+#ifdef OLAP_EXP_PHASE_CLOCKS
+    const bool clk_on = (blockIdx.x & 15) == 0 && threadIdx.x == 0;
+#endif
     auto step = [&](uint64_t tile, Regs& c, Regs& nx, Regs& n2) {
+      OLAP_CLK(c0);
       // insert tile `tile`: one returning LDS atomic + one LDS store per tuple
       uint32_t v[TPT];
 #pragma unroll
@@ -190,14 +211,24 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring(PassSrc s, uint32_t
         dmask |= (valid & !fits) ? 1u << i : 0u;  // the ring is full: this tuple is placed after the flush
       }
       if (dmask) misc[0] = (uint32_t)tile + 1u;
+#ifdef OLAP_EXP_PHASE_CLOCKS
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+      OLAP_CLK(c1);
       __syncthreads();  // ---- barrier 1: the flushers take over the rings
+      OLAP_CLK(c2);
       // Pin the schedule: tile + 1 is awaited and hashed HERE, beside the flush (the compiler otherwise moves
       // the hashing in front of barrier 1 or down to the next insert), and tile + 2 is requested only after
       // tile + 1 has arrived, so that the wait for tile + 1 (vmcnt(0)) never waits for loads issued a moment ago.
+#ifdef OLAP_EXP_PHASE_CLOCKS
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
       nx.pin();
+      OLAP_CLK(c2a);
       hash_tile(nx);
 #pragma unroll
       for (int i = 0; i < TPT; ++i) asm volatile("" : "+v"(nx.bk[i]) : : "memory");
+      OLAP_CLK(c2b);
       if (CLAIM) {  // (every VMEM operation of this wave has completed at this point)
         if (pending) {
           rsv[tb] = claimed;
@@ -210,9 +241,21 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring(PassSrc s, uint32_t
           pending = true;
         }
       }
+      OLAP_CLK(c2c);
       n2.mask = 0;
       if (tile_ok(tile + 2)) n2.template load<kProd, TILE, OLAP_RING_NT_LOAD != 0>(s, r, tile_at(tile + 2), cur);
+      OLAP_CLK(c3);
+      OLAP_CLK_ADD(CLAIM ? 0 : 1, 8, c2a - c2);
+      OLAP_CLK_ADD(CLAIM ? 0 : 1, 9, c2b - c2a);
+      OLAP_CLK_ADD(CLAIM ? 0 : 1, 10, c2c - c2b);
+      OLAP_CLK_ADD(CLAIM ? 0 : 1, 11, c3 - c2c);
       __syncthreads();  // ---- barrier 2: complete lines are out, the rings have room again
+      OLAP_CLK(c4);
+      OLAP_CLK_ADD(CLAIM ? 0 : 1, 0, c1 - c0);
+      OLAP_CLK_ADD(CLAIM ? 0 : 1, 1, c2 - c1);
+      OLAP_CLK_ADD(CLAIM ? 0 : 1, 2, c3 - c2);
+      OLAP_CLK_ADD(CLAIM ? 0 : 1, 3, c4 - c3);
+      OLAP_CLK_ADD(CLAIM ? 0 : 1, 7, 1);
       if (misc[0] == (uint32_t)tile + 1u) {  // some bucket was hot in this tile (uniform)
 #pragma unroll
         for (int i = 0; i < TPT; ++i) {
@@ -293,15 +336,24 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring(PassSrc s, uint32_t
         if (j < n) {
           const uint2 e = list[j];
           const uint4 t = *(const uint4*)(ring + e.y + 2 * (lane % LPL));
+#ifdef OLAP_EXP_NOSTORE  // timing experiment (scripts/build_variant.sh, scripts/exp_join_timing.py): everything but the line stores of the claiming (1) / capacity (2) pass
+          if ((CLAIM ? 1 : 2) != OLAP_EXP_NOSTORE || (t.x == 0x12345u && t.y == 0x6789u && t.z == 0xABCDu)) gstore4((uint4*)out + (uint64_t)e.x * LPL + (lane % LPL), t);
+#else
           if (OLAP_RING_NT_STORE) gstore4_nt((uint4*)out + (uint64_t)e.x * LPL + (lane % LPL), t);
           else gstore4((uint4*)out + (uint64_t)e.x * LPL + (lane % LPL), t);
+#endif
         }
       }
       __builtin_amdgcn_wave_barrier();
       return true;
     };
+#ifdef OLAP_EXP_PHASE_CLOCKS
+    const bool clk_on = (blockIdx.x & 15) == 0 && threadIdx.x == NPROD * kWave;
+#endif
     for (uint64_t tile = r.t0; tile < r.t1; ++tile) {
+      OLAP_CLK(f0);
       __syncthreads();  // ---- barrier 1
+      OLAP_CLK(f1);
       const uint32_t vv = owner ? cl[b_own] : 0u;
       const uint32_t total = vv & 0xFFFFu, hd = vv >> 16;
       const bool hotb = total > kRing;
@@ -327,6 +379,8 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring(PassSrc s, uint32_t
         }
         if (!flush_round(dq != kRingNone, dq, (hd + q * LINE) & (kRing - 1)) && !__ballot(q + 1 < nl)) break;
       }
+      OLAP_CLK(f1a);
+      OLAP_CLK_ADD(CLAIM ? 0 : 1, 12, f1a - f1);
       if (owner) {
         if (hotb) {  // the tuples beyond the ring: whole lines' worth goes out directly, the rest is the new residue
           const uint32_t full = total & ~(uint32_t)(LINE - 1);
@@ -374,7 +428,12 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring(PassSrc s, uint32_t
           cl[b_own] = (placed - nl * LINE) | (((hd + nl * LINE) & (kRing - 1)) << 16);
         }
       }
+      OLAP_CLK(f2);
       __syncthreads();  // ---- barrier 2
+      OLAP_CLK(f3);
+      OLAP_CLK_ADD(CLAIM ? 0 : 1, 4, f1 - f0);
+      OLAP_CLK_ADD(CLAIM ? 0 : 1, 5, f2 - f1);
+      OLAP_CLK_ADD(CLAIM ? 0 : 1, 6, f3 - f2);
       if (misc[0] == (uint32_t)tile + 1u) {
         if (CLAIM) {
           for (uint32_t q = fill_lo; q < fill_hi; q += 2) *(uint4*)(out + at(p_own, q)) = make_uint4(filler, 0u, filler, 0u);
