@@ -101,7 +101,10 @@ struct olap_ctx {
   int claim_weave = 1;     // claiming ring scatter writes woven regions (radix_kernels.h woven_at)
   int ring_interleave = -1; // ring scatter from columns: tiles dealt to the workgroups round-robin in chunks of this many (0: one contiguous run each; -1: automatic)
   int pack6 = 1;           // the last (capacity, ring) pass hands the direct-table probe 6-byte tuples {payload, low 16 hash bits} (pack6.h)
-  int ring6_tpt = 8;       // packed last pass: tuples per producer thread and tile
+  int contig_columns = 1;  // pass 0's straight-line loader addresses batches that are slices of one buffer without the pointer tables
+  int claim_lean = 1;      // claiming pass from columns: the kernel of ring_claim.h (0: ring_scatter.h's)
+  int pack6_hash = 1;      // ... and the claiming pass in front of it leaves wang_hash(key) in place of the key (one hash per tuple less)
+  int ring6_tpt = 8;       // packed last pass: tuples per producer thread and tile (8: 4096-tuple tiles flushed at once; 4: 2048-tuple tiles, the flush one tile behind the insert)
   int probe6_geometry = 0; // packed probe: 0 two workgroups of 512 per CU, 1 one workgroup of 1024
   int ring_tpt = 8;        // tuples per producer thread and tile of the ring scatter (8: 4096-tuple tiles, 4: 2048)
   int claim_mode = 1;      // pass 0 of a two-pass plan without histogram (claimed allotments): 0 off, 1 auto, 2 always
@@ -196,6 +199,7 @@ struct ColumnSet {
   ColView view{};
   std::vector<const void* const*> dev_ptr_tables;  // one device pointer table per column
   bool full_units = false;  // every batch is a whole number of units and every buffer is 16-byte aligned
+  bool contiguous = false;  // ... and in every column batch b + 1 starts where batch b ends (slices of one buffer)
   // host copies (device addresses, rows, element sizes) for views derived from this one (split_column_set)
   std::vector<std::vector<const void*>> h_ptrs;
   std::vector<uint64_t> h_rows;

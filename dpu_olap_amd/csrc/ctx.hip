@@ -177,7 +177,7 @@ int build_column_set(olap_ctx* ctx, const void* const* const* cols, int ncols,
   out->h_rows.assign(rows, rows + nb);
   out->h_elem.assign(elem_bytes, elem_bytes + ncols);
   v.row0 = nullptr;
-  bool full = nb > 0;
+  bool full = nb > 0, contiguous = nb > 0;
   for (uint64_t b = 0; b < nb; ++b) full = full && rows[b] % unit_rows == 0;
   for (int c = 0; c < ncols; ++c) {
     const void** h_ptrs = (const void**)pinned_alloc(ctx, (nb ? nb : 1) * 8);
@@ -209,11 +209,13 @@ int build_column_set(olap_ctx* ctx, const void* const* const* cols, int ncols,
       }
     }
     for (uint64_t b = 0; b < nb; ++b) full = full && (((uintptr_t)h_ptrs[b]) & 15) == 0;
+    for (uint64_t b = 0; b + 1 < nb; ++b) contiguous = contiguous && (const char*)h_ptrs[b + 1] == (const char*)h_ptrs[b] + rows[b] * elem_bytes[c];
     out->h_ptrs[(size_t)c].assign(h_ptrs, h_ptrs + nb);
     OLAP_HIP(ctx, hipMemcpyAsync(d_ptrs, h_ptrs, (nb ? nb : 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     out->dev_ptr_tables.push_back((const void* const*)d_ptrs);
   }
   out->full_units = full;
+  out->contiguous = full && contiguous;
   return OLAP_OK;
 }
 

@@ -18,6 +18,7 @@
 #include "probe_kernels.h"
 #include "radix_kernels.h"
 #include "ring_scatter.h"
+#include "ring_claim.h"
 #include "pack6.h"
 #include "radix64.h"
 
@@ -270,10 +271,35 @@ static int launch_ring_as(olap_ctx* ctx, unsigned blocks, const PassSrc& src, ui
   return OLAP_OK;
 }
 
+// the claiming ring scatter from columns rebuilt around its instruction count (ring_claim.h)
+template <int FULL, bool STOREH>
+static int launch_claim_ring_as(olap_ctx* ctx, unsigned blocks, const PassSrc& src, uint32_t shift, uint32_t fbits, uint2* out, const ClaimOut& cq) {
+  constexpr uint32_t kLds = Claim8Cfg<kRingFmax, kRingBlock, kRingProd>::kBytes;
+  auto kernel = k_part_claim_ring<kRingFmax, kRingBlock, kRingProd, 8, STOREH, FULL>;
+  OLAP_TRY(allow_lds(ctx, reinterpret_cast<const void*>(kernel), kLds));
+  char label[96];
+  std::snprintf(label, sizeof label, "olap::k_part_claim_ring<%d, %d, %d, 8, %s, %d>", kRingFmax, kRingBlock, kRingProd, STOREH ? "true" : "false", FULL);
+  ctx->phase_kernel[PH_PART_SCATTER_CLAIM] = label;
+  hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kRingBlock), kLds, ctx->stream, src, shift, fbits, out, cq);
+  OLAP_HIP(ctx, hipGetLastError());
+  return OLAP_OK;
+}
+static int launch_claim_ring(olap_ctx* ctx, unsigned blocks, const PassSrc& src, uint32_t shift, uint32_t fbits, uint2* out, const ClaimOut& cq, int full) {
+  if (cq.store_hash) {
+    if (full == 1) return launch_claim_ring_as<1, true>(ctx, blocks, src, shift, fbits, out, cq);
+    if (full == 2) return launch_claim_ring_as<2, true>(ctx, blocks, src, shift, fbits, out, cq);
+    return launch_claim_ring_as<0, true>(ctx, blocks, src, shift, fbits, out, cq);
+  }
+  if (full == 1) return launch_claim_ring_as<1, false>(ctx, blocks, src, shift, fbits, out, cq);
+  if (full == 2) return launch_claim_ring_as<2, false>(ctx, blocks, src, shift, fbits, out, cq);
+  return launch_claim_ring_as<0, false>(ctx, blocks, src, shift, fbits, out, cq);
+}
+
 // full: 0 | 1 | 2 -- column input of whole, 16-byte aligned tiles (load_tile's FULL), with / without a payload column
 static int launch_ring(olap_ctx* ctx, bool cols, bool claim, unsigned blocks, const PassSrc& src, uint32_t shift, uint32_t fbits, uint2* out,
                        const CapOut& co, const ClaimOut& cq, int full = 0) {
   const bool t4 = ctx->ring_tpt == 4;
+  if (claim && cols && !t4 && ctx->claim_lean && fbits >= 4 && !src.ord_group_bits) return launch_claim_ring(ctx, blocks, src, shift, fbits, out, cq, full);
   if (claim) {
     if (cols && !t4 && full == 1) return launch_ring_as<SRC_COLS, true, 8, 1>(ctx, blocks, src, shift, fbits, out, co, cq);
     if (cols && !t4 && full == 2) return launch_ring_as<SRC_COLS, true, 8, 2>(ctx, blocks, src, shift, fbits, out, co, cq);
@@ -286,30 +312,35 @@ static int launch_ring(olap_ctx* ctx, bool cols, bool claim, unsigned blocks, co
             : launch_ring_as<SRC_TUPLES, false, 8>(ctx, blocks, src, shift, fbits, out, co, cq);
 }
 
-// capacity-layout ring scatter with 6-byte output tuples (pack6.h)
-template <int TPT>
+// capacity-layout ring scatter with 6-byte output tuples (pack6.h).  check: the segments are not this plan's own pass-0 regions
+template <int TPT, bool CHECK, bool PIPE>
 static int launch_ring6_as(olap_ctx* ctx, unsigned blocks, const PassSrc& src, uint32_t shift, uint32_t fbits, void* out, const CapOut& co,
                            uint32_t* ptop, unsigned long long* foreign) {
   constexpr uint32_t kLds = Ring6Cfg<kRingFmax, kRingBlock, kRingProd>::kBytes;
-  auto kernel = k_part_scatter_ring6<kRingFmax, kRingBlock, kRingProd, TPT>;
+  auto kernel = k_part_scatter_ring6<kRingFmax, kRingBlock, kRingProd, TPT, CHECK, PIPE>;
   OLAP_TRY(allow_lds(ctx, reinterpret_cast<const void*>(kernel), kLds));
   char label[96];
-  std::snprintf(label, sizeof label, "olap::k_part_scatter_ring6<%d, %d, %d, %d>", kRingFmax, kRingBlock, kRingProd, TPT);
+  std::snprintf(label, sizeof label, "olap::k_part_scatter_ring6<%d, %d, %d, %d, %s, %s>", kRingFmax, kRingBlock, kRingProd, TPT, CHECK ? "true" : "false",
+                PIPE ? "true" : "false");
   ctx->phase_kernel[PH_PART_SCATTER_CAP] = label;
   hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kRingBlock), kLds, ctx->stream, src, shift, fbits, (uint16_t*)out, co, ptop, foreign);
   OLAP_HIP(ctx, hipGetLastError());
   return OLAP_OK;
 }
-static int launch_ring6(olap_ctx* ctx, unsigned blocks, const PassSrc& src, uint32_t shift, uint32_t fbits, void* out, const CapOut& co,
+static int launch_ring6(olap_ctx* ctx, bool check, unsigned blocks, const PassSrc& src, uint32_t shift, uint32_t fbits, void* out, const CapOut& co,
                         uint32_t* ptop, unsigned long long* foreign) {
-  return ctx->ring6_tpt == 4 ? launch_ring6_as<4>(ctx, blocks, src, shift, fbits, out, co, ptop, foreign)
-                             : launch_ring6_as<8>(ctx, blocks, src, shift, fbits, out, co, ptop, foreign);
+  // 2048-tuple tiles with the flush one tile behind the insert, or 4096-tuple tiles flushed at once (a ring holds 42 tuples)
+  if (ctx->ring6_tpt == 8)
+    return check ? launch_ring6_as<8, true, false>(ctx, blocks, src, shift, fbits, out, co, ptop, foreign)
+                 : launch_ring6_as<8, false, false>(ctx, blocks, src, shift, fbits, out, co, ptop, foreign);
+  return check ? launch_ring6_as<4, true, true>(ctx, blocks, src, shift, fbits, out, co, ptop, foreign)
+               : launch_ring6_as<4, false, true>(ctx, blocks, src, shift, fbits, out, co, ptop, foreign);
 }
 
 // The last pass of a side may hand the probe 6-byte tuples: capacity layout through the ring scatter, direct-address table.
 static bool pack6_ok(const olap_ctx* ctx, const PassPlan& plan, uint32_t table_bits, bool direct) {
-  return ctx->pack6 && direct && plan.passes >= 2 && table_bits >= 1 && table_bits <= 16 &&
-         ring_ok(ctx, plan.bits[plan.passes - 1], 2);
+  return ctx->pack6 && direct && plan.passes >= 2 && table_bits >= 1 && table_bits <= 16 && plan.bits[plan.passes - 1] >= 4 &&
+         ring_ok(ctx, plan.bits[plan.passes - 1], 2);  // (>= 16 buckets: the dummy rings' share of the LDS)
 }
 
 // tile-staged scatter without residues (scatter_variant = 1, A/B)
@@ -384,6 +415,10 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
     src.v = cs.view;
     src.key_ptrs = cs.dev_ptr_tables[0];
     src.pay_ptrs = has_payload ? cs.dev_ptr_tables[1] : nullptr;
+    if (cs.contiguous && ctx->contig_columns) {  // (read by the straight-line loader only, which runs when full_units holds)
+      src.contig_key = (const uint32_t*)cs.h_ptrs[0][0];
+      src.contig_pay = has_payload ? (const uint32_t*)cs.h_ptrs[1][0] : nullptr;
+    }
   }
   if (order && order->group_bits) {
     if (plan.passes != 1 || plan.bits[0] != order->owner_bits + order->group_bits + order->low_bits)
@@ -468,7 +503,11 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
       OLAP_HIP(ctx, hipMemsetAsync(cursor, 0, F * 4, ctx->stream));
       {
         PhaseScope ps(ctx, PH_PART_SCATTER_CLAIM);
-        const ClaimOut co{ccap, cursor, d_overflow, weave ? kWeaveShift : 0u, (uint32_t)(n_seg * F)};
+        // the packed last pass (pack6.h) only needs hashes: the ring scatter then leaves the hash in place of the key
+        const bool store_hash = ring_claim && cols && ctx->ring_tpt != 4 && ctx->claim_lean && fbits >= 4 && pack && ctx->pack6_hash && capm &&
+                                ring_ok(ctx, plan.bits[plan.passes - 1], 2);
+        const ClaimOut co{ccap, cursor, d_overflow, weave ? kWeaveShift : 0u, (uint32_t)(n_seg * F), store_hash ? 1u : 0u};
+        src.hashed = store_hash ? 1u : 0u;  // (read by the next pass)
 
         const bool loader_ok = cols && cs.view.unit_rows == ring_tile(ctx) && ctx->ring_full_tiles && ctx->ring_tpt != 4;
         const int full = loader_ok && cs.full_units ? (has_payload ? 1 : 2) : 0;
@@ -483,6 +522,7 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
             const uint64_t tiles = pc.view.total_units;
             if (!tiles) continue;
             PassSrc s2 = src;
+            s2.contig_key = s2.contig_pay = nullptr;
             s2.v = pc.view;
             s2.key_ptrs = pc.dev_ptr_tables[0];
             s2.pay_ptrs = has_payload ? pc.dev_ptr_tables[1] : nullptr;
@@ -528,7 +568,9 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
         if (!seg_total) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (segment totals)");
       }
       CapOut co{so->cap, so->cnt, so->dense, d_overflow, seg_total};
-      if (pack6) OLAP_TRY(launch_ring6(ctx, (unsigned)blocks, src, shift, fbits, out, co, so->top, d_foreign));
+      // (the leading hash bits of a segment are its index only when the segments are this plan's own first-pass regions)
+      const bool own_regions = claimed_input && skip_bits == 0 && !pre && plan.passes == 2 && !src.ord_group_bits;
+      if (pack6) OLAP_TRY(launch_ring6(ctx, !own_regions, (unsigned)blocks, src, shift, fbits, out, co, so->top, d_foreign));
       else if (ring_cap) OLAP_TRY(launch_ring(ctx, /*cols=*/false, false, (unsigned)blocks, src, shift, fbits, out, co, ClaimOut{}));
       else OLAP_TRY((launch_scatter<true>(ctx, /*cols=*/false, g2, fbits <= 9 && ctx->line16, (unsigned)blocks, src, shift, fbits, nullptr,
                                           nullptr, out, co)));
@@ -826,7 +868,7 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
   OLAP_HIP(ctx, hipStreamSynchronize(ctx->stream));
   counters[5] += h_foreign[0] + h_foreign[1];
   if (counters[5] && counters[2] == 0 && counters[4] == 0)
-    return ctx->fail(OLAP_ERR_INVALID, "%llu tuple(s) do not share the %d leading hash bits this join was told are fixed "
+    return ctx->fail(OLAP_ERR_INVALID, "%llu tuple(s) / thread(s) saw keys that do not share the %d leading hash bits this join was told are fixed "
                      "(olap_join_set_hash_skip_bits): the inputs were not split by owner", counters[5], ctx->hash_skip_bits);
   const bool sound = counters[2] == 0 && counters[4] == 0;  // no table / region overflow: the rows written are final
   uint64_t kept_rows = NL;
@@ -1052,6 +1094,18 @@ int olap_set_tuning(olap_ctx* ctx, const char* key, int value) {
   }
   if (!std::strcmp(key, "pack6")) {
     ctx->pack6 = value != 0;
+    return OLAP_OK;
+  }
+  if (!std::strcmp(key, "contig_columns")) {
+    ctx->contig_columns = value != 0;
+    return OLAP_OK;
+  }
+  if (!std::strcmp(key, "claim_lean")) {
+    ctx->claim_lean = value != 0;
+    return OLAP_OK;
+  }
+  if (!std::strcmp(key, "pack6_hash")) {
+    ctx->pack6_hash = value != 0;
     return OLAP_OK;
   }
   if (!std::strcmp(key, "ring6_tpt")) {

@@ -14,14 +14,16 @@
 // Layout: partition p owns the byte range [p * cap * 6, (p + 1) * cap * 6) (cap a multiple of 64 tuples, so every
 // region starts on a 128-byte line); tuple j lies at byte 6 j: payload (4 bytes, little endian), then hash & 0xFFFF.
 // Tuples straddle 16-byte vectors and 128-byte lines, so both kernels work on the region as a stream of HALFWORDS:
-//   * k_part_scatter_ring6: the ring scatter of ring_scatter.h with per-bucket rings of 128 halfwords (two lines); a tuple
-//     is a 4-byte and a 2-byte LDS store behind one returning LDS atomic (+3 on the bucket's halfword count); complete lines
-//     leave as 8 lanes x 16 B exactly as before.  42 tuples fit a ring instead of 32, so far fewer tiles take the
-//     hot-bucket detour.
+//   * k_part_scatter_ring6: the ring scatter of ring_scatter.h with per-bucket rings of 256 bytes (two lines); a tuple
+//     is three 2-byte LDS stores behind one returning LDS atomic (+6 on the bucket's byte count); complete lines
+//     leave as 8 lanes x 16 B exactly as before, but one tile behind the insert (the kernel is bound by instruction issue,
+//     not by HBM: insert and flush overlap).  42 tuples fit a ring instead of 32.
 //   * k_join_probe_direct6: every wave copies whole 16-byte vectors of its chunk (coalesced) into a private LDS
 //     staging strip and reads them back as pairs of tuples (12 bytes = 3 dwords per lane, conflict free), so loads
 //     AND result stores stay lane-contiguous.
 #pragma once
+#include <type_traits>
+
 #include "probe_kernels.h"
 #include "ring_scatter.h"
 
@@ -49,133 +51,184 @@ __host__ __device__ __forceinline__ uint32_t wang_hash_inv(uint32_t k) {
 constexpr uint32_t kPackAlign = 64;  // tuples: packed regions are whole 128-byte lines (64 x 6 B = 3 lines)
 
 // ------------------------------------------------------------------ last radix pass, 6-byte output
+// LDS: the bucket words first (a bucket's word sits at byte 4 b, its ring at kRing + (b << ring shift): both follow from ONE
+// register per tuple, the ring offset), then the rings -- F of them plus F / 16 dummy rings that swallow invalid tuples
+// (fillers, edge tiles) without a branch: 17/16 x 128 KiB for every fan-out.
 template <int FMAX, int BLOCK, int NPROD>
 struct Ring6Cfg {
-  static constexpr int kHwMin = 128;               // halfwords per bucket ring at FMAX buckets (two 128-byte lines); F buckets: FMAX * 128 / F
+  static constexpr int kRingLog2 = 17;             // all rings together: 128 KiB (FMAX buckets x two 128-byte lines)
+  static_assert(FMAX * 256 == 1 << kRingLog2, "two lines per bucket at FMAX buckets");
   static constexpr int kNW = BLOCK / kWave;
   static constexpr int kNF = kNW - NPROD;
   static constexpr int kProd = NPROD * kWave;
   static_assert(FMAX <= kNF * kWave, "one bucket per flusher lane");
   static_assert(FMAX <= BLOCK, "the closing scan runs one bucket per thread");
-  static constexpr int kDummy = 32;                // invalid tuples go to dummy counters / slots: no branches
-  static constexpr uint32_t kRingBytes = FMAX * kHwMin * 2;
-  static constexpr uint32_t kDummyOff = kRingBytes;                    // kDummy lanes x 4 halfwords
-  static constexpr uint32_t kCl = kDummyOff + kDummy * 8;              // per bucket: halfwords in the ring | ring head << 16
-  static constexpr uint32_t kHot = kCl + (FMAX + kDummy) * 4;          // per bucket: hot-tile hand-off {base, full | head << 16}
-  static constexpr int kListPerWave = (FMAX / kNF) * (kHwMin / 64);    // a wave's buckets x lines per ring: the same for every fan-out
-  static constexpr uint32_t kList = kHot + FMAX * 8;                   // per flusher wave: lines to emit {line index, ring byte offset}
-  static constexpr uint32_t kMisc = kList + kNF * kListPerWave * 8;    // [0] hot flag, [1] the segment's leading hash bits, scan scratch
-  static constexpr uint32_t kBytes = kMisc + kNW * 8 + 64;
+  static constexpr int kSlots = FMAX + FMAX / 16;
+  static constexpr uint32_t kCl = 0;                                   // per ring: bytes in the ring | ring head << 16
+  static constexpr uint32_t kMisc = 2304;                              // [0] hot flag, [1] the segment's leading hash bits, scan scratch
+  static_assert(kSlots * 4 <= kMisc, "bucket words");
+  static constexpr uint32_t kHot = kMisc + 64 + kNW * 8;               // per bucket: hot-tile hand-off {base, full | head << 16}
+  static constexpr int kListPerWave = (FMAX / kNF) * 2;                // a wave's buckets x lines per ring: the same for every fan-out
+  static constexpr uint32_t kList = kHot + FMAX * 8;                   // per flusher wave: lines to emit {line index, ring address}
+  static constexpr uint32_t kRing = (kList + kNF * kListPerWave * 8 + 4095) / 4096 * 4096;
+  static constexpr uint32_t kBytes = kRing + (kSlots << 8);
+  static_assert(kRing < 65536, "the ring area's offset is an immediate of the LDS stores");
 };
 
 // Capacity layout only (one workgroup per input segment, CapOut), tuple input only.  out: the packed regions as halfwords.
-// ptop[seg * F + b] = the hash bits above `shift` that every tuple of partition (seg, b) carries; *foreign counts tuples
-// of a segment that disagree about the bits above the pass's field (a violated olap_join_set_hash_skip_bits promise).
-template <int FMAX, int BLOCK, int NPROD, int TPT>
+// ptop[seg * F + b] = the hash bits above `shift` that every tuple of partition (seg, b) carries.  CHECK: the input's
+// segments are not this plan's own pass-0 regions (skipped hash bits, pre-split input) -- the leading bits are then
+// taken from the tuples, and *foreign counts threads that saw tuples of one segment disagree about them (a violated
+// olap_join_set_hash_skip_bits promise); otherwise they are the segment's index.
+template <int FMAX, int BLOCK, int NPROD, int TPT, bool CHECK, bool PIPE>
 __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring6(PassSrc s, uint32_t shift, uint32_t fbits, uint16_t* out, CapOut co,
                                                                 uint32_t* ptop, unsigned long long* foreign) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using C = Ring6Cfg<FMAX, BLOCK, NPROD>;
   constexpr int kNF = C::kNF, kProd = C::kProd;
   constexpr int TILE = kProd * TPT;
-  constexpr uint32_t LHW = 64;        // halfwords per 128-byte line
+  constexpr uint32_t LB = 128;        // bytes per line
   constexpr int LPL = 8;              // lanes per line (16 B each)
   constexpr int LPI = kWave / LPL;    // lines per store instruction
-  uint16_t* ring = (uint16_t*)smem;
   uint32_t* cl = (uint32_t*)(smem + C::kCl);
   uint2* hot = (uint2*)(smem + C::kHot);
   uint32_t* misc = (uint32_t*)(smem + C::kMisc);
+  char* rings = smem + C::kRing;
   const uint32_t F = 1u << fbits;
-  const uint32_t RB = (uint32_t)(FMAX * C::kHwMin) >> fbits;  // halfwords per bucket ring (a power of two >= 128)
+  const uint32_t rsh = (uint32_t)C::kRingLog2 - fbits;  // log2 of a ring's bytes (>= 8)
+  const uint32_t RB = 1u << rsh, M = RB - 1u;
+  const uint32_t nd = F >= 16u ? F >> 4 : 1u;           // dummy rings
   const TileRange r = block_tiles<SRC_TUPLES, TILE>(s);
   const unsigned lane = lane_id();
   const unsigned wave = threadIdx.x / kWave;
-  const uint32_t cap_hw = co.cap * 3u;  // halfwords per region (the host keeps it below 2^32)
-  for (uint32_t b = threadIdx.x; b < FMAX + C::kDummy; b += BLOCK) cl[b] = 0;
+  const uint32_t cap_l = co.cap * 3u / 64u;  // lines per region (cap is a multiple of 64 tuples; the host keeps P * cap_l below 2^32)
+  for (uint32_t b = threadIdx.x; b < F + nd; b += BLOCK) cl[b] = 0;
   if (threadIdx.x == 0) {
     misc[0] = 0;
-    misc[1] = kRingNone;
+    misc[1] = CHECK ? kRingNone : r.seg;
   }
   __syncthreads();
-  uint32_t mytop = kRingNone, bad = 0;  // leading hash bits of the first tuple this thread saw; tuples that differ from it
+  uint32_t acc_or = 0, acc_and = 0xFFFFFFFFu;  // CHECK: OR / AND of the hashes of the valid tuples this thread saw
 
   if (wave < (unsigned)NPROD) {
     // ------------------------------------------------------------ producers
     const uint32_t expect = r.seg & s.chk_mask;
-    const uint32_t dummy = FMAX + (lane & (C::kDummy - 1));
-    const uint32_t dummy_hw = C::kDummyOff / 2 + (lane & (C::kDummy - 1)) * 4;
-    const uint32_t top_shift = shift + fbits;  // < 32 (host)
+    const uint32_t dummy_bs = (F + (lane & (nd - 1u))) << rsh;  // ring offset of this lane's dummy ring
+    const uint32_t lim = RB - 6u;                               // a tuple fits while the ring holds at most this many bytes
     using Regs = TileRegs<TPT, SRC_TUPLES, 0>;
-    // bk[i] = bucket << 16 | low 16 hash bits (the key itself is not needed after this)
+    // k[i] <- ring offset of the tuple's bucket (or dummy ring), bk[i] <- its hash (the low 16 bits are what is stored)
+    const uint32_t chk_bits = (uint32_t)__popc(s.chk_mask);  // (the mask is a run of low bits, or 0: every tuple in range is real)
     auto hash_tile = [&](Regs& t) {
+      auto body = [&](auto use_mask, auto hashed) {
 #pragma unroll
-      for (int i = 0; i < TPT; ++i) {
-        const uint32_t h = wang_hash(t.k[i]);
-        const bool ok = (((t.mask >> i) & 1u) != 0) & (((h >> s.chk_shift) & s.chk_mask) == expect);
-        t.bk[i] = ((ok ? ((h >> shift) & (F - 1u)) : dummy) << 16) | (h & 0xFFFFu);
-        const uint32_t tp = h >> top_shift;
-        mytop = (ok & (mytop == kRingNone)) ? tp : mytop;
-        bad += (ok & (tp != mytop)) ? 1u : 0u;
+        for (int i = 0; i < TPT; ++i) {
+          const uint32_t h = decltype(hashed)::value ? t.k[i] : wang_hash(t.k[i]);  // (hashed: the first pass left the hash in place of the key)
+          bool ok = __builtin_amdgcn_ubfe(h, s.chk_shift, chk_bits) == expect;
+          if (decltype(use_mask)::value) ok &= ((t.mask >> i) & 1u) != 0;
+          t.k[i] = ok ? __builtin_amdgcn_ubfe(h, shift, fbits) << rsh : dummy_bs;
+          t.bk[i] = h;
+          if (CHECK) {
+            acc_or |= ok ? h : 0u;
+            acc_and &= ok ? h : 0xFFFFFFFFu;
+          }
+        }
+      };
+      const bool whole = t.mask == (1u << TPT) - 1u;  // (uniform: whole tiles do not look at the mask again)
+      if (s.hashed) {
+        if (whole) body(std::false_type{}, std::true_type{});
+        else body(std::true_type{}, std::true_type{});
+      } else {
+        if (whole) body(std::false_type{}, std::false_type{});
+        else body(std::true_type{}, std::false_type{});
       }
     };
     ColsCursor cur;
     Regs A, B, Cc;
     A.mask = B.mask = Cc.mask = 0;
 #pragma unroll
-    for (int i = 0; i < TPT; ++i) A.bk[i] = B.bk[i] = Cc.bk[i] = dummy << 16;
+    for (int i = 0; i < TPT; ++i) A.k[i] = B.k[i] = Cc.k[i] = dummy_bs;
     if (r.t0 < r.t1) A.template load<kProd, TILE, false>(s, r, r.t0, cur);
     if (r.t0 + 1 < r.t1) B.template load<kProd, TILE, false>(s, r, r.t0 + 1, cur);
     hash_tile(A);
-    auto hw_of = [](uint32_t pay, uint32_t bkh, int j) -> uint16_t { return j == 0 ? (uint16_t)pay : j == 1 ? (uint16_t)(pay >> 16) : (uint16_t)bkh; };
+    auto hw_of = [](uint32_t pay, uint32_t h, int j) -> uint16_t { return j == 0 ? (uint16_t)pay : j == 1 ? (uint16_t)(pay >> 16) : (uint16_t)h; };
+#ifdef OLAP_EXP_PHASE_CLOCKS
+    const bool clk_on = (blockIdx.x & 15) == 0 && threadIdx.x == 0;
+#endif
     auto step = [&](uint64_t tile, Regs& c, Regs& nx, Regs& n2) {
-      // insert tile `tile`: one returning LDS atomic, one 4-byte and one 2-byte LDS store per tuple
+      OLAP_CLK(c0);
+      // insert tile `tile`: one returning LDS atomic and three 2-byte LDS stores per tuple
       uint32_t v[TPT];
 #pragma unroll
-      for (int i = 0; i < TPT; ++i) v[i] = atomicAdd(&cl[c.bk[i] >> 16], 3u);
-      uint32_t dmask = 0;
+      for (int i = 0; i < TPT; ++i) v[i] = atomicAdd((uint32_t*)(smem + C::kCl + (c.k[i] >> (rsh - 2u))), 6u);
+      uint32_t mx = 0;
 #pragma unroll
-      for (int i = 0; i < TPT; ++i) {
-        const uint32_t b = c.bk[i] >> 16, cnt = v[i] & 0xFFFFu, hd = v[i] >> 16;
-        const bool valid = b < (uint32_t)FMAX;
-        // The tuple's 6 bytes start on a halfword: an aligned dword and a halfword -- {payload | hash} from an even start,
-        // {payload low | payload high : hash} from an odd one (the ring head is a multiple of 64, so the count's parity is the
-        // start's, and the dword fits the ring as a whole or not at all).  The pieces may lie on both sides of the ring's wrap.
-        const bool odd = (cnt & 1u) != 0;
-        const uint32_t pay = c.p[i], h16 = c.bk[i] & 0xFFFFu;
-        const uint32_t q32 = cnt + (odd ? 1u : 0u), q16 = cnt + (odd ? 0u : 2u);
-        const uint32_t v32 = odd ? ((pay >> 16) | (h16 << 16)) : pay;
-        const uint32_t v16 = odd ? pay : h16;
-        const uint32_t a32 = (valid & (q32 < RB)) ? b * RB + ((hd + q32) & (RB - 1)) : dummy_hw;
-        const uint32_t a16 = (valid & (q16 < RB)) ? b * RB + ((hd + q16) & (RB - 1)) : dummy_hw + 2;
-        *(uint32_t*)(ring + a32) = v32;
-        ring[a16] = (uint16_t)v16;
-        dmask |= (valid & (cnt + 3u > RB)) ? 1u << i : 0u;  // (part of) this tuple is placed after the flush
+      for (int i = 0; i < TPT; ++i) mx = max(mx, v[i] & 0xFFFFu);
+      uint32_t dmask = 0;
+      if (!__ballot(mx > lim)) {  // every tuple of this wave fits its ring (dummy rings are reset every tile): no selects
+#pragma unroll
+        for (int i = 0; i < TPT; ++i) {
+          const uint32_t p = (v[i] >> 16) + (v[i] & 0xFFFFu), bs = c.k[i];
+          *(uint16_t*)(rings + (bs | (p & M))) = (uint16_t)c.p[i];
+          *(uint16_t*)(rings + (bs | ((p + 2u) & M))) = (uint16_t)(c.p[i] >> 16);
+          *(uint16_t*)(rings + (bs | ((p + 4u) & M))) = (uint16_t)c.bk[i];
+        }
+      } else {  // a ring of this wave overflows (or a dummy ring ran over in an edge tile): halfword by halfword
+#pragma unroll
+        for (int i = 0; i < TPT; ++i) {
+          const uint32_t cnt = v[i] & 0xFFFFu, hd = v[i] >> 16, bs = c.k[i];
+          const bool valid = bs < (F << rsh);
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            const uint32_t q = cnt + 2u * j;
+            // what lies beyond the ring is placed after the flush; a dummy ring just wraps
+            const uint32_t at = (!valid | (q < RB)) ? (bs | ((hd + q) & M)) : (dummy_bs | (2u * j));
+            *(uint16_t*)(rings + at) = hw_of(c.p[i], c.bk[i], j);
+          }
+          dmask |= (valid & (cnt > lim)) ? 1u << i : 0u;
+        }
+        if (dmask) misc[0] = (uint32_t)tile + 1u;
       }
-      if (dmask) misc[0] = (uint32_t)tile + 1u;
-      __syncthreads();  // ---- barrier 1: the flushers take over the rings
+#ifdef OLAP_EXP_PHASE_CLOCKS
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+      OLAP_CLK(c1);
+      __syncthreads();  // ---- barrier 1: this tile's inserts are in the rings
+      OLAP_CLK(c2);
+#ifdef OLAP_EXP_PHASE_CLOCKS
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+      OLAP_CLK(c2a);
       nx.pin();
       hash_tile(nx);
 #pragma unroll
-      for (int i = 0; i < TPT; ++i) asm volatile("" : "+v"(nx.bk[i]) : : "memory");
+      for (int i = 0; i < TPT; ++i) asm volatile("" : "+v"(nx.k[i]) : : "memory");
       n2.mask = 0;
       if (tile + 2 < r.t1) n2.template load<kProd, TILE, false>(s, r, tile + 2, cur);
-      __syncthreads();  // ---- barrier 2: complete lines are out, the rings have room again
+      OLAP_CLK(c3);
+      __syncthreads();  // ---- barrier 2: the rings' words are up to date
+      OLAP_CLK(c4);
+      OLAP_CLK_ADD(1, 0, c1 - c0);
+      OLAP_CLK_ADD(1, 1, c2 - c1);
+      OLAP_CLK_ADD(1, 2, c3 - c2);
+      OLAP_CLK_ADD(1, 3, c4 - c3);
+      OLAP_CLK_ADD(1, 8, c2a - c2);
       if (misc[0] == (uint32_t)tile + 1u) {  // some bucket was hot in this tile (uniform)
+        OLAP_CLK_ADD(1, 9, 1);
 #pragma unroll
         for (int i = 0; i < TPT; ++i) {
           if (dmask & (1u << i)) {
-            const uint32_t b = c.bk[i] >> 16;
+            const uint32_t bs = c.k[i], b = bs >> rsh;
             const uint2 info = hot[b];
             const uint32_t full = info.y & 0xFFFFu, hd = info.y >> 16, cnt = v[i] & 0xFFFFu;
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-              const uint32_t q = cnt + j;
+              const uint32_t q = cnt + 2u * j;
               if (q < RB) continue;  // already in the ring (flushed with it)
               const uint16_t val = hw_of(c.p[i], c.bk[i], j);
               if (q < full) {  // straight to the range the owner reserved (dropped when the region is full)
-                if (info.x != kRingNone) gstore_t(out + ((uint64_t)r.seg * F + b) * cap_hw + info.x + (q - RB), val);
+                if (info.x != kRingNone) gstore_t(out + (((uint64_t)r.seg * F + b) * cap_l * LB + info.x + (q - RB)) / 2u, val);
               } else {         // tail of the tile: the bucket's new residue
-                ring[b * RB + ((hd + (q - full)) & (RB - 1))] = val;
+                *(uint16_t*)(rings + (bs | ((hd + (q - full)) & M))) = val;
               }
             }
           }
@@ -196,32 +249,20 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring6(PassSrc s, uint32_
     const uint32_t bpw = F >= (uint32_t)kNF ? F / kNF : 1u;  // buckets per flusher wave: consecutive buckets, consecutive lanes
     const uint32_t b_own = fw * bpw + lane;
     const bool owner = lane < bpw && b_own < F;
-    const uint64_t p_own = (uint64_t)r.seg * F + b_own;
+    const uint32_t p_own = r.seg * F + b_own;
+    const uint32_t line0 = p_own * cap_l;                    // the region's first line
+    const uint32_t ring_own = C::kRing + (b_own << rsh);     // LDS address of the bucket's ring
     uint2* list = (uint2*)(smem + C::kList) + fw * C::kListPerWave;
-    uint32_t pos = 0;     // next line's halfword offset in the region
+    uint32_t pos = 0;     // next line of the region
     bool dead = !owner;   // region exhausted (skew): tuples are dropped, *overflow raised
     // The flush runs ONE TILE BEHIND the insert: the lines that are complete after tile t are listed between the two barriers
     // of tile t and leave (LDS -> HBM) while the producers insert tile t + 1; they stay in the ring until the bookkeeping of
     // tile t + 1 releases them.  `pend`: this owner's lines listed for the coming emission; n_list: the wave's.
     uint32_t pend = 0, n_list = 0;
-    const uint32_t lines_per_ring = RB / LHW;
-    uint32_t nplanes = 1;
-    while ((1u << nplanes) <= lines_per_ring) ++nplanes;  // bit planes of a per-owner line count
-    // exclusive prefix of x over the wave's lanes (+ the wave's total) from ballots of x's bit planes
-    auto wave_rank = [&](uint32_t x, uint32_t& total) -> uint32_t {
-      const unsigned long long below = (1ull << lane) - 1ull;
-      uint32_t rank = 0;
-      total = 0;
-      for (uint32_t bit = 0; bit < nplanes; ++bit) {
-        const unsigned long long m = __ballot((x >> bit) & 1u);
-        rank += (uint32_t)__popcll(m & below) << bit;
-        total += (uint32_t)__popcll(m) << bit;
-      }
-      return rank;
-    };
+    const uint32_t lines_per_ring = RB / LB;
     // The wave emits the listed lines eight per store instruction, kFU instructions' worth at a time -- list entries, then
     // ring reads, then stores, each kind back to back, so that a batch costs two LDS round trips instead of two per instruction.
-    constexpr int kFU = 4;
+    constexpr int kFU = TPT >= 8 ? 4 : 2;
     auto emit_lines = [&](uint32_t n) {
       for (uint32_t k0 = 0; k0 < n; k0 += LPI * kFU) {
         uint2 e[kFU];
@@ -240,11 +281,20 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring6(PassSrc s, uint32_
         }
       }
     };
-    // lists `count` lines of this owner: ring lines from halfword `ring0` on, output from `pos` on
-    auto list_lines = [&](uint32_t rank, uint32_t count, uint32_t ring0) {
-      for (uint32_t q = 0; q < count; ++q)
-        list[rank + q] = make_uint2((uint32_t)((p_own * cap_hw + pos + q * LHW) / LHW), (b_own * RB + ((ring0 + q * LHW) & (RB - 1))) * 2u);
-      pos += count * LHW;
+    // Lists `count` lines of every owner (ring lines from byte `ring0` on, output from line `pos` on) in rounds: round q takes
+    // line q of the owners that have one (a ballot and a lane count per round; two rounds at 512 buckets).  Returns the total.
+    auto list_rounds = [&](uint32_t count, uint32_t ring0) -> uint32_t {
+      uint32_t n = 0;
+      for (uint32_t q = 0;; ++q) {
+        const bool has = count > q;
+        const unsigned long long m = __ballot(has);
+        if (!m) break;
+        if (has) list[n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] =
+            make_uint2(line0 + pos + q, ring_own + ((ring0 + q * LB) & M));
+        n += (uint32_t)__popcll(m);
+      }
+      pos += count;
+      return n;
     };
 #ifdef OLAP_EXP_PHASE_CLOCKS
     const bool clk_on = (blockIdx.x & 15) == 0 && threadIdx.x == NPROD * kWave;
@@ -256,65 +306,74 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring6(PassSrc s, uint32_
       __syncthreads();  // ---- barrier 1: the inserts of this tile are in the rings
       OLAP_CLK(f1);
       const uint32_t vv = owner ? cl[b_own] : 0u;
+      if (fw == 0 && lane < nd) cl[F + lane] = 0;  // the dummy rings start every tile empty
       const uint32_t tot0 = vv & 0xFFFFu, hd0 = vv >> 16;
-      const bool hotb = tot0 > RB;  // (the window of this tile's insert: RB halfwords from hd0, the listed lines included)
-      if (__ballot(hotb)) {
-        // A hot bucket's ring is exactly full; its first `pend` lines have just left.  The rest leaves NOW, so that the
-        // ring is empty for what did not fit; whole lines' worth of that goes out directly, the rest is the new residue.
-        uint32_t imm = 0;
-        if (hotb && !dead) {
-          imm = lines_per_ring - pend;
-          if ((uint64_t)pos + imm * LHW > cap_hw) {
-            dead = true;
-            atomicAdd(co.overflow, 1ull);
-            imm = 0;
+      const uint32_t cnt1 = tot0 - pend * LB;  // release the lines that went out during the insert
+      const uint32_t hd1 = (hd0 + pend * LB) & M;
+      const uint32_t nl = cnt1 / LB;           // complete lines now: they go out during the next insert
+      uint32_t mine = nl;
+      // (tot0 > RB: the window of this tile's insert -- RB bytes from hd0, the listed lines included -- was overrun)
+      if (__ballot(owner & ((tot0 > RB) | dead | (pos + nl > cap_l)))) {  // rare: a hot bucket, an exhausted region
+        const bool hotb = tot0 > RB;
+        if (__ballot(hotb)) {
+          // A hot bucket's ring is exactly full; its first `pend` lines have just left.  The rest leaves NOW, so that the
+          // ring is empty for what did not fit; whole lines' worth of that goes out directly, the rest is the new residue.
+          uint32_t imm = 0;
+          if (hotb && !dead) {
+            imm = lines_per_ring - pend;
+            if (pos + imm > cap_l) {
+              dead = true;
+              atomicAdd(co.overflow, 1ull);
+              imm = 0;
+            }
+          }
+          const uint32_t n_imm = list_rounds(imm, hd0 + pend * LB);
+          __builtin_amdgcn_wave_barrier();
+          emit_lines(n_imm);
+          __builtin_amdgcn_wave_barrier();
+          if (hotb) {
+            const uint32_t full = tot0 & ~(LB - 1);
+            const uint32_t ndl = (full - RB) / LB;  // lines that go out directly
+            uint32_t dbase = kRingNone;
+            if (ndl && !dead) {
+              if (pos + ndl > cap_l) {
+                dead = true;
+                atomicAdd(co.overflow, 1ull);
+              } else {
+                dbase = pos * LB;
+                pos += ndl;
+              }
+            }
+            hot[b_own] = make_uint2(dbase, full | (hd0 << 16));
+            cl[b_own] = (tot0 - full) | (hd0 << 16);
           }
         }
-        uint32_t n_imm;
-        const uint32_t rank = wave_rank(imm, n_imm);
-        list_lines(rank, imm, hd0 + pend * LHW);
-        __builtin_amdgcn_wave_barrier();
-        emit_lines(n_imm);
-        __builtin_amdgcn_wave_barrier();
-        if (hotb) {
-          const uint32_t full = tot0 & ~(LHW - 1);
-          const uint32_t nd = full - RB;
-          uint32_t dbase = kRingNone;
-          if (nd && !dead) {
-            if ((uint64_t)pos + nd > cap_hw) {
+        mine = 0;
+        if (owner && !hotb) {
+          if (nl && !dead) {
+            if (pos + nl > cap_l) {
               dead = true;
               atomicAdd(co.overflow, 1ull);
             } else {
-              dbase = pos;
-              pos += nd;
+              mine = nl;
             }
           }
-          hot[b_own] = make_uint2(dbase, full | (hd0 << 16));
-          cl[b_own] = (tot0 - full) | (hd0 << 16);
-          pend = 0;
+          if (dead || !PIPE) cl[b_own] = (cnt1 - nl * LB) | (((hd1 + nl * LB) & M) << 16);  // dropped (or, not pipelined, emitted) at once
+          else cl[b_own] = cnt1 | (hd1 << 16);
         }
+      } else if (owner) {
+        cl[b_own] = PIPE ? cnt1 | (hd1 << 16) : (cnt1 - nl * LB) | (((hd1 + nl * LB) & M) << 16);
       }
-      uint32_t mine = 0, hd1 = 0;
-      if (owner && !hotb) {
-        const uint32_t cnt1 = tot0 - pend * LHW;  // release the lines that went out during the insert
-        hd1 = (hd0 + pend * LHW) & (RB - 1);
-        const uint32_t nl = cnt1 / LHW;           // complete lines now: they go out during the next insert
-        if (nl && !dead) {
-          if ((uint64_t)pos + nl * LHW > cap_hw) {
-            dead = true;
-            atomicAdd(co.overflow, 1ull);
-          } else {
-            mine = nl;
-          }
-        }
-        if (dead) cl[b_own] = (cnt1 - nl * LHW) | (((hd1 + nl * LHW) & (RB - 1)) << 16);  // dropped at once
-        else cl[b_own] = cnt1 | (hd1 << 16);
+      n_list = list_rounds(mine, hd1);
+      if (PIPE) {
         pend = mine;
+      } else {  // large tiles (a ring cannot hold a tile's lines beside the next tile's tuples): the lines leave at once
+        __builtin_amdgcn_wave_barrier();
+        emit_lines(n_list);
+        n_list = 0;
       }
-      const uint32_t rank = wave_rank(mine, n_list);
-      list_lines(rank, mine, hd1);
       OLAP_CLK(f2);
-      __syncthreads();  // ---- barrier 2: the rings' counts are up to date
+      __syncthreads();  // ---- barrier 2: the rings' words are up to date
       OLAP_CLK(f3);
       OLAP_CLK_ADD(1, 4, f1 - f0a);
       OLAP_CLK_ADD(1, 5, f2 - f1);
@@ -328,29 +387,29 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring6(PassSrc s, uint32_
     // tail: what is left in the rings (less than a line per bucket)
     if (owner) {
       const uint32_t vv = cl[b_own];
-      const uint32_t rr = (vv & 0xFFFFu) - pend * LHW, hd = ((vv >> 16) + pend * LHW) & (RB - 1);
-      uint16_t* region = out + p_own * cap_hw;
-      uint32_t count_hw = pos;
+      const uint32_t rr = (vv & 0xFFFFu) - pend * LB, hd = ((vv >> 16) + pend * LB) & M;
+      uint32_t count_b = pos * LB;
       if (!dead) {
-        if ((uint64_t)pos + rr > cap_hw) {
+        if (rr && pos >= cap_l) {
           atomicAdd(co.overflow, 1ull);
         } else {
-          for (uint32_t j = 0; j < rr; ++j) region[pos + j] = ring[b_own * RB + ((hd + j) & (RB - 1))];
-          count_hw = pos + rr;
+          uint16_t* dst = out + ((uint64_t)(line0 + pos) * LB) / 2u;
+          for (uint32_t j = 0; j < rr; j += 2) dst[j / 2] = *(const uint16_t*)(smem + ring_own + ((hd + j) & M));
+          count_b += rr;
         }
       }
-      ((uint32_t*)hot)[b_own] = count_hw / 3u;  // tuples, for the closing scan
+      ((uint32_t*)hot)[b_own] = count_b / 6u;  // tuples, for the closing scan
     }
   }
   // partition sizes, dense starts and leading hash bits (exclusive scan over this segment's buckets, one per thread)
-  if (mytop != kRingNone) misc[1] = mytop;  // (any of the segment's tuples: they all agree, or `foreign` says so)
+  if (CHECK && acc_and != 0xFFFFFFFFu) misc[1] = acc_or >> (shift + fbits);  // (any thread's: they all agree, or `foreign` says so)
   __syncthreads();
   const uint32_t segtop = misc[1];
-  if (mytop != kRingNone && mytop != segtop) ++bad;
-  if (bad) atomicAdd(foreign, (unsigned long long)bad);
+  if (CHECK && acc_and != 0xFFFFFFFFu && (((acc_or ^ acc_and) >> (shift + fbits)) != 0 || (acc_or >> (shift + fbits)) != segtop))
+    atomicAdd(foreign, 1ull);
   const uint32_t t = threadIdx.x;
   const uint64_t count = t < F ? ((const uint32_t*)hot)[t] : 0u;
-  uint64_t* wtot = (uint64_t*)(smem + C::kMisc + 16);
+  uint64_t* wtot = (uint64_t*)(smem + C::kMisc + 64);
   uint64_t incl = count;
 #pragma unroll
   for (int o = 1; o < kWave; o <<= 1) {

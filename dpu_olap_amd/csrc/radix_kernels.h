@@ -38,6 +38,9 @@ struct PassSrc {
   const void* const* key_ptrs;
   const void* const* pay_ptrs;  // may be null: payload = global row index
   uint64_t tiles_per_block;
+  // SRC_COLS, straight-line loader only: the batches are consecutive slices of one buffer per column, starting here (null: use the tables)
+  const uint32_t* contig_key;
+  const uint32_t* contig_pay;
   uint32_t interleave;  // ring scatter: workgroup w takes tiles w, w + grid, w + 2 grid, ... (0: a contiguous run of tiles_per_block)
   // SRC_TUPLES
   const uint2* tuples;
@@ -69,6 +72,9 @@ struct PassSrc {
   uint32_t ord_owner_bits;
   uint32_t ord_group_bits;  // 0: natural order
   uint32_t ord_low_bits;
+  // SRC_TUPLES: the tuples hold wang_hash(key) in place of the key (ClaimOut::store_hash of the pass that wrote them; read
+  // by k_part_scatter_ring6 only, whose packed output never needs the key itself)
+  uint32_t hashed;
 };
 
 // Bucket of a tuple in a pass: the bits [shift, shift + log2 F) of its hash, in the pass's bucket order.
@@ -308,32 +314,47 @@ template <int BLOCK, int TILE, bool HASPAY, bool NT>
 __device__ __forceinline__ void load_tile_full(const PassSrc& s, uint64_t tile, ColsCursor& cur, u32x4_t& k0, u32x4_t& k1, u32x4_t& p0,
                                                u32x4_t& p1) {
   static_assert(TILE / BLOCK == 8, "two key and two payload vectors per thread");
-  Loc l;
-  if (tile == cur.tile + 1 && cur.local_unit + 1 < cur.units) {
-    l.batch = cur.batch;
-    l.local_unit = cur.local_unit + 1;
+  const uint32_t* kbase;
+  const uint32_t* pbase = nullptr;
+  uint32_t row_first;
+  if (s.contig_key) {
+    // The batches are consecutive slices of ONE buffer per column (ColumnSet::contiguous; record batches cut from a
+    // table): tile t starts t * TILE elements into it -- no batch lookup, no pointer table (whose dependent loads cost a
+    // round trip to the L2 in front of the data loads at every change of batch).
+    kbase = s.contig_key + tile * (uint64_t)TILE;
+    if (HASPAY) pbase = s.contig_pay + tile * (uint64_t)TILE;
+    row_first = (uint32_t)(tile * (uint64_t)TILE);
   } else {
-    l = locate(s.v, tile);
+    Loc l;
+    if (tile == cur.tile + 1 && cur.local_unit + 1 < cur.units) {
+      l.batch = cur.batch;
+      l.local_unit = cur.local_unit + 1;
+    } else {
+      l = locate(s.v, tile);
+    }
+    cur.tile = tile;
+    cur.local_unit = l.local_unit;
+    if (l.batch != cur.batch) {  // workgroup-uniform
+      cur.batch = l.batch;
+      cur.kp = (const uint32_t*)uniform_u64((uint64_t)s.key_ptrs[l.batch]);
+      if (HASPAY) cur.pp = (const uint32_t*)uniform_u64((uint64_t)s.pay_ptrs[l.batch]);
+      cur.row0 = uniform_u64(batch_row0(s.v, l.batch));
+      cur.units = uniform_u64(batch_rows(s.v, l.batch)) / TILE;
+    }
+    const uint64_t r0 = l.local_unit * TILE;
+    kbase = cur.kp + r0;
+    if (HASPAY) pbase = cur.pp + r0;
+    row_first = (uint32_t)(cur.row0 + r0);
   }
-  cur.tile = tile;
-  cur.local_unit = l.local_unit;
-  if (l.batch != cur.batch) {  // workgroup-uniform
-    cur.batch = l.batch;
-    cur.kp = (const uint32_t*)uniform_u64((uint64_t)s.key_ptrs[l.batch]);
-    if (HASPAY) cur.pp = (const uint32_t*)uniform_u64((uint64_t)s.pay_ptrs[l.batch]);
-    cur.row0 = uniform_u64(batch_row0(s.v, l.batch));
-    cur.units = uniform_u64(batch_rows(s.v, l.batch)) / TILE;
-  }
-  const uint64_t r0 = l.local_unit * TILE;
-  const OLAP_GLOBAL u32x4_t* kp = (const OLAP_GLOBAL u32x4_t*)(cur.kp + r0) + threadIdx.x;
+  const OLAP_GLOBAL u32x4_t* kp = (const OLAP_GLOBAL u32x4_t*)kbase + threadIdx.x;
   k0 = NT ? __builtin_nontemporal_load(kp) : kp[0];
   k1 = NT ? __builtin_nontemporal_load(kp + BLOCK) : kp[BLOCK];
   if (HASPAY) {
-    const OLAP_GLOBAL u32x4_t* pp = (const OLAP_GLOBAL u32x4_t*)(cur.pp + r0) + threadIdx.x;
+    const OLAP_GLOBAL u32x4_t* pp = (const OLAP_GLOBAL u32x4_t*)pbase + threadIdx.x;
     p0 = NT ? __builtin_nontemporal_load(pp) : pp[0];
     p1 = NT ? __builtin_nontemporal_load(pp + BLOCK) : pp[BLOCK];
   } else {
-    const uint32_t i0 = (uint32_t)(cur.row0 + r0) + threadIdx.x * 4;
+    const uint32_t i0 = row_first + threadIdx.x * 4;
     p0.x = i0;
     p0.y = i0 + 1;
     p0.z = i0 + 2;
@@ -845,6 +866,8 @@ struct ClaimOut {
   unsigned long long* overflow;
   uint32_t weave_shift;  // != 0: woven regions (woven_at; cap is then a multiple of the chunk); ring scatter only
   uint32_t weave_n;      // n_seg * F
+  uint32_t store_hash;   // ring scatter only: the tuples written hold wang_hash(key) in place of the key (the hash is a bijection;
+                         // the consumer -- the packed last pass, pack6.h -- then skips its own hashing)
 };
 #ifndef OLAP_CLAIM_CHUNK
 #define OLAP_CLAIM_CHUNK 128

@@ -77,6 +77,7 @@ struct TileRegs {
   uint32_t mask;
   __device__ __forceinline__ uint32_t key(int i) const { return k[i]; }
   __device__ __forceinline__ uint32_t pay(int i) const { return p[i]; }
+  __device__ __forceinline__ void set_key(int i, uint32_t v) { k[i] = v; }
   template <int BLOCK, int TILE, bool NT>
   __device__ __forceinline__ void load(const PassSrc& s, const TileRange& r, uint64_t tile, ColsCursor& cur) {
     mask = load_tile<SRC, BLOCK, true, TILE, NT>(s, r, tile, cur, k, p);
@@ -93,6 +94,10 @@ struct TileRegsFull {
   uint32_t bk[TPT];
   uint32_t mask;
   __device__ __forceinline__ uint32_t key(int i) const { return i < 4 ? k0[i & 3] : k1[i & 3]; }
+  __device__ __forceinline__ void set_key(int i, uint32_t v) {
+    if (i < 4) k0[i & 3] = v;
+    else k1[i & 3] = v;
+  }
   __device__ __forceinline__ uint32_t pay(int i) const { return i < 4 ? p0[i & 3] : p1[i & 3]; }
   template <int BLOCK, int TILE, bool NT>
   __device__ __forceinline__ void load(const PassSrc& s, const TileRange&, uint64_t tile, ColsCursor& cur) {

@@ -57,7 +57,7 @@ def main():
         buf = (ctypes.c_ulonglong * 32)()
         assert ctx.lib.olap_debug_ring_clocks(buf) == 0
         names = ["P insert", "P wait b1", "P hash+load", "P wait b2", "F wait b1", "F flush", "F wait b2", "tiles",
-                 "P wait tile+1 | F6 scan", "P hash | F6 list", "P claims | F6 emit", "P load issue | F6 lines", "F line rounds"]
+                 "P wait tile+1", "P hash | hot tiles (ring6)", "P claims | F emit (ring6)", "P load issue | F lines (ring6)", "hot tiles (claim)", "F list (claim)", "F emit (claim)", "F lines (claim)"]
         for role, label in ((0, "claim pass"), (1, "capacity pass")):
             v = list(buf[role * 16:role * 16 + 16])
             if v[7]:

@@ -40,9 +40,11 @@ def test_join_sf2048_digest():
     assert st["passes"] == 2 and st["nr_partitions"] == 1 << 18 and st["max_build_rows"] <= st["table_slots"]
     assert d["dtype"] == "u32" and d["roofline"]["bound"] == "hbm" and d["cold_first_step_ms"] > 0
     names = {k["phase"]: k["kernel"] for k in d["kernels"]}
-    assert names["join-probe"] == "olap::k_join_probe_direct"
-    assert names["partition-scatter-claim"].startswith("olap::k_part_scatter_ring<0, true")       # pass 0 from the Arrow columns
-    assert names["partition-scatter-capacity"].startswith("olap::k_part_scatter_ring<1, false")   # last pass, capacity layout
+    # pass 0 from the Arrow columns (hashes in place of the keys, straight-line loader), last pass with 6-byte tuples in the
+    # capacity layout, probe over packed partitions (csrc/ring_claim.h, csrc/pack6.h)
+    assert names["partition-scatter-claim"].startswith("olap::k_part_claim_ring<") and names["partition-scatter-claim"].endswith("true, 1>")
+    assert names["partition-scatter-capacity"].startswith("olap::k_part_scatter_ring6<")
+    assert names["join-probe"].startswith("olap::k_join_probe_direct6<") and names["join-probe"].endswith("true, true>")
 
 
 @pytest.mark.parametrize("op,lines", [("filter", 2), ("sum", 3), ("take", 3)])

@@ -32,11 +32,11 @@ def owned_keys(n, owner, skip_bits=2, mult=2654435761, add=12345):
     return c[:n]
 
 
-def run_join(dev, fk, y, pk, x, rows, skip_bits, drop=False, knobs=None):
+def run_join(dev, fk, y, pk, x, rows, skip_bits, drop=False, knobs=None, radix_bits=16):
     """8 + 8 radix bits below `skip_bits` fixed ones -> 14 table bits: claiming pass 0, capacity-layout last pass, direct table.
     rows(n) -> batch lengths.  Returns (host columns, stats, (last-pass kernel, probe kernel), (attempts, overflows))."""
     o = _ops()
-    defaults = {"pack6": 1, "probe6_geometry": 0, "probe_slices": 1}
+    defaults = {"pack6": 1, "probe6_geometry": 0, "probe_slices": 1, "ring6_tpt": 8, "pack6_hash": 1, "claim_lean": 1, "contig_columns": 1}
     d, out = {}, {}
     try:
         d = {k: dev.to_device(v) for k, v in (("fk", fk), ("y", y), ("pk", pk), ("x", x))}
@@ -48,7 +48,7 @@ def run_join(dev, fk, y, pk, x, rows, skip_bits, drop=False, knobs=None):
                 at += r
             assert at == n
             return res
-        dev.join_configure(16, 8)
+        dev.join_configure(radix_bits, 8)
         dev.set_tuning("claim_mode", 2)
         dev.join_set_hash_skip_bits(skip_bits)
         for k, v in (knobs or {}).items():
@@ -202,3 +202,61 @@ def test_join_packed_generator_shape_sf64_digest(dev, pack):
     assert dev.checksum_rows3_u32(out["fk"].ptr, out["y"].ptr, out["x"].ptr, n) == expect
     for c in list(cols.values()) + list(out.values()):
         dev.release(o.DeviceArray(c.ptr, 0))
+
+
+@pytest.mark.parametrize("knobs", [{"ring6_tpt": 4}, {"ring6_tpt": 4, "pack6_hash": 0}, {"ring6_tpt": 8, "pack6_hash": 0}, {"claim_lean": 0}, {"contig_columns": 0}],
+                         ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()))
+@pytest.mark.parametrize("shape", ["uniform", "clustered_left"])
+def test_join_packed_tuples_kernel_variants(dev, shape, knobs):
+    """The other builds of the packed path on 2^25 x 2^25 rows: 2048-tuple tiles with the flush one tile behind the insert
+    (ring6_tpt = 4), keys instead of hashes between the passes (pack6_hash = 0), ring_scatter.h's claiming kernel in front
+    (claim_lean = 0), the pointer tables instead of the one-buffer addressing (contig_columns = 0)."""
+    n = 1 << 25
+    rng = np.random.default_rng(21)
+    pk = owned_keys(n, owner=3)
+    x = rng.integers(0, 1 << 32, size=n, dtype=np.uint32)
+    idx = rng.integers(0, n, size=n)
+    fk, exp_x = pk[idx], x[idx]
+    if shape == "clustered_left":
+        order = np.argsort(oracle.wang_hash_np(fk), kind="stable")
+        fk, exp_x = fk[order], exp_x[order]
+    y = np.arange(n, dtype=np.uint32)
+    (ofk, oy, ox), stats, kernels, counters = run_join(dev, fk, y, pk, x, even_batches(32), 2, knobs=knobs)
+    assert "k_part_scatter_ring6" in kernels[0] and f", {knobs.get('ring6_tpt', 8)}, true, " in kernels[0], kernels
+    assert kernels[1].endswith("true, true>") and counters == (1, 0) and stats["missing_keys"] == 0, (kernels, counters, stats)
+    np.testing.assert_array_equal(np.sort(oy), y)
+    np.testing.assert_array_equal(fk[oy], ofk)
+    np.testing.assert_array_equal(exp_x[oy], ox)
+
+
+@pytest.mark.parametrize("tpt", [8, 4])
+@pytest.mark.parametrize("shape", ["uniform", "clustered_both", "ragged_misses"])
+def test_join_packed_tuples_128_buckets(dev, shape, tpt):
+    """An 8 + 7 bit plan below 3 skipped hash bits (2^24 x 2^24 rows of one owner of an 8-way split): the last pass has 128
+    buckets -- rings of eight lines, eight dummy rings, several lines per bucket and tile in the flusher's rounds."""
+    n = 1 << 24
+    rng = np.random.default_rng(31)
+    pk = owned_keys(n, owner=5, skip_bits=3)
+    x = rng.integers(0, 1 << 32, size=n, dtype=np.uint32)
+    idx = rng.integers(0, n, size=n)
+    fk, exp_x = pk[idx], x[idx]
+    keep = np.ones(n, dtype=bool)
+    if shape == "ragged_misses":
+        extra = owned_keys(n + (n >> 5), owner=5, skip_bits=3)[n:]
+        where = rng.choice(n, size=extra.size, replace=False)
+        fk[where] = extra
+        keep[where] = False
+    if shape == "clustered_both":
+        order = np.argsort(oracle.wang_hash_np(fk), kind="stable")
+        fk, exp_x = fk[order], exp_x[order]
+        order = np.argsort(oracle.wang_hash_np(pk), kind="stable")
+        pk, x = pk[order], x[order]
+    y = np.arange(n, dtype=np.uint32)
+    rows = ragged_batches(17) if shape == "ragged_misses" else even_batches(16)
+    (ofk, oy, ox), stats, kernels, counters = run_join(dev, fk, y, pk, x, rows, 3, drop=(shape == "ragged_misses"), knobs={"ring6_tpt": tpt}, radix_bits=15)
+    assert stats["radix_bits"][:2] == [8, 7] and stats["table_slots"] == 1 << 14, stats
+    assert "k_part_scatter_ring6" in kernels[0] and kernels[1].endswith("true, true>") and counters == (1, 0), (kernels, counters)
+    assert stats["missing_keys"] == int((~keep).sum()) and ofk.size == int(keep.sum())
+    np.testing.assert_array_equal(np.sort(oy), y[keep])
+    np.testing.assert_array_equal(fk[oy], ofk)
+    np.testing.assert_array_equal(exp_x[oy], ox)
