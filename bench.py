@@ -130,6 +130,19 @@ def cpu_baseline(cores_hint: int, cpu_sf: int):
     return out, arrow
 
 
+def alg_bytes_per_unit(phase, kernel, default):
+    """Algorithmic bytes per tuple (radix passes) or per row pair (probe) of the kernel that served `phase`: what it has to
+    read and write given the tuple formats on either side of it.  The packed kernels of csrc/pack6.h move 6-byte tuples
+    {payload, low 16 hash bits}: the last radix pass reads 8 and writes 6 bytes per tuple, the probe reads 6 (or 8) bytes per
+    side and writes the 12-byte result row."""
+    if "k_part_scatter_ring6" in kernel:
+        return 8 + 6
+    if "k_join_probe_direct6" in kernel:
+        flags = kernel[kernel.index("<") + 1:kernel.rindex(">")].replace(" ", "").split(",")[-2:]
+        return sum(6 if f == "true" else 8 for f in flags) + 12
+    return default
+
+
 def main():
     args = parse()
     import torch
@@ -290,7 +303,7 @@ def main():
         # rocprofv3 PMC passes of this same command (scripts/profile_bench.sh -> profiles/), only for the config they were
         # taken on, else null.
         traffic_src, traffic_by_kernel = None, {}
-        for cand in ("r2_traffic_sf2048.json", "r1_traffic_sf2048.json"):
+        for cand in ("r3_traffic_sf2048.json", "r2_traffic_sf2048.json", "r1_traffic_sf2048.json"):
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", cand)))
             except Exception:
@@ -303,9 +316,9 @@ def main():
             if ph not in alg_per_unit or not v["launches"]:
                 continue
             avg_ms = v["ms"] / v["launches"]
-            alg = alg_per_unit[ph] * n_local
-            ach = alg / (avg_ms * 1e-3) / 1e9
             name = ctx.phase_kernel(ph)
+            alg = alg_bytes_per_unit(ph, name, alg_per_unit[ph]) * n_local
+            ach = alg / (avg_ms * 1e-3) / 1e9
             kernels.append({"phase": ph, "kernel": name, "launches_per_step": v["launches"] / args.steps, "avg_launch_ms": round(avg_ms, 4),
                             "total_ms_per_step": round(v["ms"] / args.steps, 3), "algorithmic_bytes_per_launch": alg,
                             "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBPS, 4),

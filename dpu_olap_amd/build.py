@@ -42,8 +42,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
     cc = hipcc()
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "radix_kernels.h"), os.path.join(CSRC, "probe_kernels.h"), os.path.join(CSRC, "ring_scatter.h"), os.path.join(CSRC, "radix64.h"), os.path.join(CSRC, "join64.h"), os.path.join(ROOT, "include", "olap_gpu.h"), os.path.join(ROOT, "include", "olap_arrow.h"),
-               os.path.abspath(__file__)]
+    import glob
+    headers = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(ROOT, "include", "olap_gpu.h"), os.path.join(ROOT, "include", "olap_arrow.h"),
+                                                               os.path.abspath(__file__)]
     jobs = []
     objs = []
     for s in SOURCES:
