@@ -21,6 +21,7 @@
 #include "ring_claim.h"
 #include "pack6.h"
 #include "radix64.h"
+#include "ring64.h"
 
 namespace olap {
 
@@ -1106,6 +1107,11 @@ int olap_set_tuning(olap_ctx* ctx, const char* key, int value) {
   }
   if (!std::strcmp(key, "pack6_hash")) {
     ctx->pack6_hash = value != 0;
+    return OLAP_OK;
+  }
+  if (!std::strcmp(key, "join64_ring")) {
+    if (value < 0 || value > 2) return ctx->fail(OLAP_ERR_INVALID, "join64_ring must be 0, 1 or 2");
+    ctx->join64_ring = value;
     return OLAP_OK;
   }
   if (!std::strcmp(key, "ring6_tpt")) {

@@ -6,9 +6,9 @@
 
 namespace olap {
 
-static int make_plan64(olap_ctx* ctx, uint32_t total_bits, PassPlan* plan) {
+static int make_plan64(olap_ctx* ctx, uint32_t total_bits, PassPlan* plan, int min_passes = 1) {
   if (total_bits < 1) total_bits = 1;
-  const int passes = ((int)total_bits + k64MaxFBits - 1) / k64MaxFBits;
+  const int passes = std::max(min_passes, ((int)total_bits + k64MaxFBits - 1) / k64MaxFBits);
   if (passes > kMaxPasses) return ctx->fail(OLAP_ERR_INVALID, "%u radix bits need %d passes (max %d)", total_bits, passes, kMaxPasses);
   plan->passes = passes;
   plan->total_bits = total_bits;
@@ -104,13 +104,110 @@ static int partition_side64(olap_ctx* ctx, const ColumnSet& cs, bool has_payload
   return OLAP_OK;
 }
 
+// ---- the histogram-free plan (ring64.h): two ring-scatter passes on 12-byte tuples, capacity-layout probe
+using K64RingCfg = Ring64Cfg<kRingFmax, kRingBlock, kRingProd>;
+constexpr int k64RingTpt = 4;  // 2048-tuple tiles: a 256-byte ring (512 buckets) holds 21 tuples, a tile brings 4 on average
+
+// Region size of pass 0 (tuples, a multiple of the allotment): the average bucket, 8 sigma (uniform hash) and the allotments the
+// workgroups may leave unused -- per workgroup and bucket the one in use, the reserve and a claim in flight.  0: does not fit.
+static uint32_t claim_cap64(const olap_ctx* ctx, uint64_t rows, uint64_t F) {
+  const uint64_t kb = (uint64_t)ctx->compute_units * 3;
+  const uint64_t avg = (rows + F - 1) / F;
+  uint64_t sd = 1;
+  while (sd * sd < avg) ++sd;
+  const uint64_t cap = align_up(avg + avg / 64 + 8 * sd + (kb + 2) * k64Allot, k64Allot);
+  return (cap >= (1ull << 32) || cap / 32 * 3 * F >= (1ull << 32)) ? 0u : (uint32_t)cap;  // (line indices are 32-bit)
+}
+static uint32_t region_cap64(uint64_t rows, uint64_t P) { return (uint32_t)align_up(region_cap(rows, P), k64CapAlign); }
+
+// join64_ring tuning: 0 never, 1 (default) two-pass plans whose worst-case padding stays below half of the rows, 2 every two-pass plan
+static bool ring64_eligible(const olap_ctx* ctx, uint64_t NL, uint64_t NR, const PassPlan& plan) {
+  if (!ctx->join64_ring || plan.passes != 2) return false;
+  for (int i = 0; i < 2; ++i)
+    if (plan.bits[i] < 4 || (1u << plan.bits[i]) > (uint32_t)kRingFmax) return false;
+  const uint64_t F0 = 1ull << plan.bits[0], P = 1ull << plan.total_bits;
+  if (!claim_cap64(ctx, NL, F0) || !claim_cap64(ctx, NR, F0)) return false;
+  if (region_cap64(NL, P) / 32ull * 3 * P >= (1ull << 32) || region_cap64(NR, P) / 32ull * 3 * P >= (1ull << 32)) return false;
+  if (ctx->join64_ring >= 2) return true;
+  const uint64_t pad = (uint64_t)ctx->compute_units * 3 * k64Allot * F0;  // worst case; what is written as fillers is about a third of it
+  return pad <= NL / 2 && pad <= NR / 2;
+}
+
+struct Side12 {
+  uint32_t cap = 0;
+  uint32_t* cnt = nullptr;
+  uint64_t* dense = nullptr;
+  const Tuple12* t = nullptr;
+};
+
+static uint64_t side_scratch_bytes64_ring(uint64_t F0, uint64_t P) {
+  return align_up(F0 * 4, 256) + align_up(F0 * 8, 256) + align_up(P * 4, 256) + align_up(P * 8, 256) + 1024;
+}
+
+// both passes of one side: columns -> claimed regions in `tmp` -> capacity layout in `fin`
+static int partition_side64_ring(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, const PassPlan& plan, uint32_t* tmp, uint32_t* fin,
+                                 unsigned long long* d_overflow, Side12* so) {
+  const uint64_t rows = cs.view.total_rows;
+  const uint32_t b0 = plan.bits[0], b1 = plan.bits[1];
+  const uint64_t F0 = 1ull << b0, F1 = 1ull << b1, P = F0 * F1;
+  const uint32_t cap0 = claim_cap64(ctx, rows, F0), cap1 = region_cap64(rows, P);
+  uint32_t* cursor = (uint32_t*)ws_alloc(ctx, F0 * 4);
+  uint64_t* seg_total = (uint64_t*)ws_alloc(ctx, F0 * 8);
+  so->cnt = (uint32_t*)ws_alloc(ctx, P * 4);
+  so->dense = (uint64_t*)ws_alloc(ctx, P * 8);
+  so->cap = cap1;
+  so->t = (const Tuple12*)fin;
+  if (!cursor || !seg_total || !so->cnt || !so->dense || !cap0) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (64-bit ring passes)");
+  OLAP_HIP(ctx, hipMemsetAsync(cursor, 0, F0 * 4, ctx->stream));
+  auto claim_kernel = k64_ring<true, kRingFmax, kRingBlock, kRingProd, k64RingTpt>;
+  auto cap_kernel = k64_ring<false, kRingFmax, kRingBlock, kRingProd, k64RingTpt>;
+  OLAP_TRY(allow_lds(ctx, reinterpret_cast<const void*>(claim_kernel), K64RingCfg::kBytes));
+  OLAP_TRY(allow_lds(ctx, reinterpret_cast<const void*>(cap_kernel), K64RingCfg::kBytes));
+  {  // pass 0: one workgroup per CU, a contiguous run of tiles each
+    PassSrc src{};
+    src.v = cs.view;
+    src.key_ptrs = cs.dev_ptr_tables[0];
+    src.pay_ptrs = has_payload ? cs.dev_ptr_tables[1] : nullptr;
+    const uint64_t tiles = cs.view.total_units;
+    const uint64_t nb = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)ctx->compute_units, tiles));
+    src.tiles_per_block = std::max<uint64_t>(1, (tiles + nb - 1) / nb);
+    const uint64_t blocks = std::max<uint64_t>(1, (tiles + src.tiles_per_block - 1) / src.tiles_per_block);
+    const ClaimOut cq{cap0, cursor, d_overflow, 0u, (uint32_t)F0, 0u};
+    PhaseScope ps(ctx, PH_PART_SCATTER_CLAIM);
+    ctx->phase_kernel[PH_PART_SCATTER_CLAIM] = "olap::k64_ring<true, 512, 1024, 8, 4>";
+    hipLaunchKernelGGL(claim_kernel, dim3((unsigned)blocks), dim3(kRingBlock), K64RingCfg::kBytes, ctx->stream, src, 32u - b0, b0, tmp, CapOut{}, cq);
+    OLAP_HIP(ctx, hipGetLastError());
+  }
+  {  // pass 1: one workgroup per pass-0 bucket
+    PassSrc src{};
+    src.tuples = reinterpret_cast<const uint2*>(tmp);
+    src.seg_cnt = cursor;
+    src.seg_cap = cap0;
+    src.chk_shift = 32u - b0;
+    src.chk_mask = (uint32_t)F0 - 1u;
+    src.n_seg = (uint32_t)F0;
+    src.blocks_per_seg = 1;
+    const CapOut co{cap1, so->cnt, so->dense, d_overflow, seg_total};
+    PhaseScope ps(ctx, PH_PART_SCATTER_CAP);
+    ctx->phase_kernel[PH_PART_SCATTER_CAP] = "olap::k64_ring<false, 512, 1024, 8, 4>";
+    hipLaunchKernelGGL(cap_kernel, dim3((unsigned)F0), dim3(kRingBlock), K64RingCfg::kBytes, ctx->stream, src, 32u - b0 - b1, b1, fin, co, ClaimOut{});
+    OLAP_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_dense_fix, dim3((unsigned)F0), dim3(1024), 0, ctx->stream, (const uint64_t*)seg_total, (uint32_t)F1, so->dense);
+    OLAP_HIP(ctx, hipGetLastError());
+  }
+  return OLAP_OK;
+}
+
 static int join64_once(olap_ctx* ctx, const uint64_t* const* lfk, const uint32_t* const* ly, const uint64_t* lrows, uint64_t lnb,
                        const uint64_t* const* rpk, const uint32_t* const* rx, const uint64_t* rrows, uint64_t rnb, int in_mem, uint64_t NL,
                        uint64_t NR, uint32_t total_bits, uint64_t* out_fk, uint32_t* out_y, uint32_t* out_x, int out_mem,
-                       olap_join_stats* st, unsigned long long counters[4], uint64_t* rows_out) {
+                       olap_join_stats* st, unsigned long long counters[4], uint64_t* rows_out, bool ring, bool* ring_overflow) {
   PassPlan plan;
-  OLAP_TRY(make_plan64(ctx, total_bits, &plan));
+  // (join64_ring = 2: 8 or 9 bits are split over two passes as well, so that the ring plan can be exercised at small sizes)
+  OLAP_TRY(make_plan64(ctx, total_bits, &plan, ring && ctx->join64_ring >= 2 && total_bits >= 8 && total_bits <= (uint32_t)k64MaxFBits ? 2 : 1));
   const uint32_t P = 1u << plan.total_bits;
+  ring = ring && ring64_eligible(ctx, NL, NR, plan);
+  *ring_overflow = false;
   const uint32_t eb[2] = {8, 4};
   const bool l_pay = ly != nullptr, r_pay = rx != nullptr;
   const void* const* lcols[2] = {(const void* const*)lfk, (const void* const*)ly};
@@ -118,24 +215,34 @@ static int join64_once(olap_ctx* ctx, const uint64_t* const* lfk, const uint32_t
   const uint64_t maxN = std::max(NL, NR);
   const bool drop = ctx->join_drop_unmatched != 0;
   const uint64_t miss_words = (NL + 31) / 32 + 2, cseg = (NL + kCompactSeg - 1) / kCompactSeg;
-  uint64_t need = column_set_bytes(lrows, lnb, l_pay ? 2 : 1, eb, in_mem) + column_set_bytes(rrows, rnb, r_pay ? 2 : 1, eb, in_mem) +
-                  side_scratch_bytes64(ctx, NL, lnb, plan) + side_scratch_bytes64(ctx, NR, rnb, plan) + align_up((NL + 1) * 16, 256) +
-                  align_up((NR + 1) * 16, 256) + 8192;
+  uint64_t need = column_set_bytes(lrows, lnb, l_pay ? 2 : 1, eb, in_mem) + column_set_bytes(rrows, rnb, r_pay ? 2 : 1, eb, in_mem) + 8192;
   need += align_up((NL / kProbeSlice + 2) * 8, 256) + 256;  // probe slice list
-  if (plan.passes >= 2) need += align_up((maxN + 1) * 16, 256);
-  if (plan.passes >= 3) need += align_up((maxN + 1) * 16, 256);
+  const uint64_t F0 = 1ull << plan.bits[0];
+  uint64_t tmp_bytes = 0, lfin_bytes = 0, rfin_bytes = 0;  // ring plan: claimed regions (one side at a time), capacity regions per side
+  if (ring) {
+    tmp_bytes = align_up((uint64_t)std::max(claim_cap64(ctx, NL, F0), claim_cap64(ctx, NR, F0)) * F0 * k64TupleBytes, 256);
+    lfin_bytes = align_up((uint64_t)region_cap64(NL, P) * P * k64TupleBytes, 256);
+    rfin_bytes = align_up((uint64_t)region_cap64(NR, P) * P * k64TupleBytes, 256);
+    need += tmp_bytes + lfin_bytes + rfin_bytes + 2 * side_scratch_bytes64_ring(F0, P);
+  } else {
+    need += side_scratch_bytes64(ctx, NL, lnb, plan) + side_scratch_bytes64(ctx, NR, rnb, plan) + align_up((NL + 1) * 16, 256) +
+            align_up((NR + 1) * 16, 256);
+    if (plan.passes >= 2) need += align_up((maxN + 1) * 16, 256);
+    if (plan.passes >= 3) need += align_up((maxN + 1) * 16, 256);
+  }
   if (out_mem == OLAP_MEM_HOST) need += align_up(NL * 8 + 8, 256) + 2 * align_up(NL * 4 + 4, 256);
   if (drop) need += align_up(miss_words * 4, 256) + align_up(cseg * 4, 256) + align_up((cseg + 1) * 8, 256) + align_up(NL * 8 + 8, 256);
   OLAP_TRY(pinned_begin(ctx, (lnb + rnb + 2) * 8 * 8 + (cseg + 1) * 12 + 8192));
   OLAP_TRY(ws_begin(ctx, need));
   ColumnSet lcs, rcs;
-  OLAP_TRY(build_column_set(ctx, lcols, l_pay ? 2 : 1, eb, lrows, lnb, in_mem, k64Tile, &lcs));
-  OLAP_TRY(build_column_set(ctx, rcols, r_pay ? 2 : 1, eb, rrows, rnb, in_mem, k64Tile, &rcs));
-  uint4* tmp0 = plan.passes >= 2 ? (uint4*)ws_alloc(ctx, (maxN + 1) * 16) : nullptr;
-  uint4* tmp1 = plan.passes >= 3 ? (uint4*)ws_alloc(ctx, (maxN + 1) * 16) : nullptr;
-  uint4* Lt = (uint4*)ws_alloc(ctx, (NL + 1) * 16);
-  uint4* Rt = (uint4*)ws_alloc(ctx, (NR + 1) * 16);
-  unsigned long long* d_cnt = (unsigned long long*)ws_alloc(ctx, 32);
+  const uint32_t unit_rows = ring ? (uint32_t)(kRingProd * kWave * k64RingTpt) : (uint32_t)k64Tile;
+  OLAP_TRY(build_column_set(ctx, lcols, l_pay ? 2 : 1, eb, lrows, lnb, in_mem, unit_rows, &lcs));
+  OLAP_TRY(build_column_set(ctx, rcols, r_pay ? 2 : 1, eb, rrows, rnb, in_mem, unit_rows, &rcs));
+  uint4* tmp0 = ring ? (uint4*)ws_alloc(ctx, tmp_bytes) : plan.passes >= 2 ? (uint4*)ws_alloc(ctx, (maxN + 1) * 16) : nullptr;
+  uint4* tmp1 = !ring && plan.passes >= 3 ? (uint4*)ws_alloc(ctx, (maxN + 1) * 16) : nullptr;
+  uint4* Lt = (uint4*)ws_alloc(ctx, ring ? lfin_bytes : (NL + 1) * 16);
+  uint4* Rt = (uint4*)ws_alloc(ctx, ring ? rfin_bytes : (NR + 1) * 16);
+  unsigned long long* d_cnt = (unsigned long long*)ws_alloc(ctx, 64);  // [0..3] the probe's counters, [4] region overflows of the ring passes
   uint64_t* d_fk = out_fk;
   uint32_t *d_y = out_y, *d_x = out_x;
   if (out_mem == OLAP_MEM_HOST) {
@@ -143,9 +250,9 @@ static int join64_once(olap_ctx* ctx, const uint64_t* const* lfk, const uint32_t
     d_y = (uint32_t*)ws_alloc(ctx, NL * 4 + 4);
     d_x = (uint32_t*)ws_alloc(ctx, NL * 4 + 4);
   }
-  if ((plan.passes >= 2 && !tmp0) || (plan.passes >= 3 && !tmp1) || !Lt || !Rt || !d_cnt || !d_fk || !d_y || !d_x)
+  if ((plan.passes >= 2 && !tmp0) || (!ring && plan.passes >= 3 && !tmp1) || !Lt || !Rt || !d_cnt || !d_fk || !d_y || !d_x)
     return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (64-bit join buffers)");
-  OLAP_HIP(ctx, hipMemsetAsync(d_cnt, 0, 32, ctx->stream));
+  OLAP_HIP(ctx, hipMemsetAsync(d_cnt, 0, 64, ctx->stream));
   uint32_t* miss_bits = nullptr;
   if (drop) {
     miss_bits = (uint32_t*)ws_alloc(ctx, miss_words * 4);
@@ -153,11 +260,26 @@ static int join64_once(olap_ctx* ctx, const uint64_t* const* lfk, const uint32_t
     OLAP_HIP(ctx, hipMemsetAsync(miss_bits, 0, miss_words * 4, ctx->stream));
   }
   const uint64_t *loff = nullptr, *roff = nullptr;
-  OLAP_TRY(partition_side64(ctx, lcs, l_pay, plan, tmp0, tmp1, Lt, &loff));
-  OLAP_TRY(partition_side64(ctx, rcs, r_pay, plan, tmp0, tmp1, Rt, &roff));
+  Side12 ls, rs;
+  if (ring) {
+    OLAP_TRY(partition_side64_ring(ctx, lcs, l_pay, plan, (uint32_t*)tmp0, (uint32_t*)Lt, d_cnt + 4, &ls));
+    OLAP_TRY(partition_side64_ring(ctx, rcs, r_pay, plan, (uint32_t*)tmp0, (uint32_t*)Rt, d_cnt + 4, &rs));
+    // a region overflowed (skew): nothing below is trusted, the caller redoes the join with the exact layout
+    unsigned long long h_over = 0;
+    OLAP_HIP(ctx, hipMemcpyAsync(&h_over, d_cnt + 4, 8, hipMemcpyDeviceToHost, ctx->stream));
+    OLAP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->last_join_region_overflows = h_over;
+    if (h_over) {
+      *ring_overflow = true;
+      return resolve_timers(ctx);
+    }
+  } else {
+    OLAP_TRY(partition_side64(ctx, lcs, l_pay, plan, tmp0, tmp1, Lt, &loff));
+    OLAP_TRY(partition_side64(ctx, rcs, r_pay, plan, tmp0, tmp1, Rt, &roff));
+  }
   {
     PhaseScope ps(ctx, PH_JOIN_PROBE);
-    ctx->phase_kernel[PH_JOIN_PROBE] = "olap::k64_probe";
+    ctx->phase_kernel[PH_JOIN_PROBE] = ring ? "olap::k64_probe12" : "olap::k64_probe";
     const uint64_t grid = std::min<uint64_t>((uint64_t)ctx->compute_units * 8, P);
     ProbeSlices slices{nullptr, nullptr, 0};  // probe partitions longer than one slice (a hot foreign key) become several work items
     if (ctx->probe_slices) {
@@ -166,11 +288,15 @@ static int join64_once(olap_ctx* ctx, const uint64_t* const* lfk, const uint32_t
       slices.count = (uint32_t*)ws_alloc(ctx, 16);
       if (!slices.list || !slices.count) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (probe slices)");
       OLAP_HIP(ctx, hipMemsetAsync(slices.count, 0, 16, ctx->stream));
-      const PartView lv{nullptr, loff, nullptr, nullptr, 0};
+      const PartView lv{nullptr, loff, ls.cnt, ls.dense, ls.cap, nullptr};
       hipLaunchKernelGGL(k_probe_slices, dim3((P + 255) / 256), dim3(256), 0, ctx->stream, lv, P, slices);
     }
-    hipLaunchKernelGGL(k64_probe, dim3((unsigned)grid), dim3(k64Block), 0, ctx->stream, (const uint4*)Rt, roff, (const uint4*)Lt, loff, P, d_fk,
-                       d_y, d_x, d_cnt, miss_bits, slices);
+    if (ring)
+      hipLaunchKernelGGL(k64_probe12, dim3((unsigned)grid), dim3(k64Block), 0, ctx->stream, Part12{rs.t, rs.cnt, rs.dense, rs.cap},
+                         Part12{ls.t, ls.cnt, ls.dense, ls.cap}, P, d_fk, d_y, d_x, d_cnt, miss_bits, slices);
+    else
+      hipLaunchKernelGGL(k64_probe, dim3((unsigned)grid), dim3(k64Block), 0, ctx->stream, (const uint4*)Rt, roff, (const uint4*)Lt, loff, P, d_fk,
+                         d_y, d_x, d_cnt, miss_bits, slices);
     OLAP_HIP(ctx, hipGetLastError());
   }
   OLAP_HIP(ctx, hipMemcpyAsync(counters, d_cnt, 32, hipMemcpyDeviceToHost, ctx->stream));
@@ -253,9 +379,17 @@ extern "C" int olap_join_u64(olap_ctx* ctx, const uint64_t* const* left_fk_ptrs,
   if (ctx->radix_bits_total < 0 && bits < (uint32_t)k64MaxFBits && NL >= (1ull << 22)) bits = k64MaxFBits;
   unsigned long long counters[4] = {0, 0, 0, 0};
   uint64_t kept_rows = NL;
-  for (int attempt = 0; attempt < 4; ++attempt) {
+  bool ring = true;  // the histogram-free plan where it applies; a region overflow (skew) falls back to the exact layout
+  ctx->last_join_attempts = 0;
+  for (int attempt = 0; attempt < 6; ++attempt) {
+    bool ring_overflow = false;
+    ++ctx->last_join_attempts;
     OLAP_TRY(join64_once(ctx, left_fk_ptrs, left_y_ptrs, left_rows, n_left_batches, right_pk_ptrs, right_x_ptrs, right_rows, n_right_batches,
-                         in_mem, NL, NR, bits, out_fk, out_y, out_x, out_mem, stats, counters, &kept_rows));
+                         in_mem, NL, NR, bits, out_fk, out_y, out_x, out_mem, stats, counters, &kept_rows, ring, &ring_overflow));
+    if (ring_overflow) {
+      ring = false;
+      continue;
+    }
     if (counters[2] == 0) break;
     bits += 2;  // a build partition overflowed the LDS table: split finer and retry
     if (bits > 30) break;

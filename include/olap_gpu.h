@@ -309,6 +309,10 @@ int olap_join_configure(olap_ctx* ctx, int radix_bits_total, int max_bits_per_pa
  *                      whole-tile loader, as contiguous runs otherwise) | 0 contiguous runs | N round-robin in chunks of N tiles
  *   claim_weave        1 the claiming ring scatter weaves its regions in 64 KiB chunks, so that the lines the chip writes at
  *                      any moment lie within ~32 MiB (address-translation locality; default) | 0 regions one after the other
+ *   join64_ring        1 olap_join_u64: two-pass plans of large inputs run without histograms on 12-byte tuples -- claiming ring
+ *                      scatter from the columns, capacity-layout ring scatter, capacity-layout probe (csrc/ring64.h; default) |
+ *                      0 always the exact-layout pipeline (histogram + scan + scatter per pass, 16-byte tuples) | 2 every plan of
+ *                      8..18 radix bits (tests)
  *   direct_table       1 direct-address LDS table when <= 14 hash bits remain (default) | 0 probing table
  *   take_variant       0 automatic | 1 never the LDS-window kernel | 3 small gather tiles | 4 window-bucketed path
  *                      for batches whose data buffer is far larger than LDS (an alternative that measured slower)

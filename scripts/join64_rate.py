@@ -19,10 +19,12 @@ def main():
     ap.add_argument("--log2-rows", type=int, default=27)
     ap.add_argument("--log2-batch", type=int, default=21)
     ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--ring", type=int, default=1, help="join64_ring tuning: 0 exact-layout pipeline, 1 automatic, 2 forced")
     a = ap.parse_args()
     n, br = 1 << a.log2_rows, 1 << a.log2_batch
     nb = n // br
     ctx = capi.Context(0)
+    ctx.set_tuning("join64_ring", a.ring)
     rng = np.random.default_rng(3)
     odd = np.uint64(0x9E3779B97F4A7C15)
     rows = np.arange(n, dtype=np.uint64)
@@ -55,7 +57,8 @@ def main():
     # compulsory bytes per row pair: 12 + 12 read, 16 written
     print(json.dumps({"metric": "join_u64 rows/s (left rows per second)", "rows_per_side": n, "ms_per_join": round(ms, 3),
                       "value_Grows_s": round(n / ms / 1e6, 2), "algorithmic_GBps": round(n * 40 / ms / 1e6, 1), "verified": bool(ok),
-                      "stats": stats, "phase_ms": tm}))
+                      "moved_bytes_per_pair": 136 if "probe12" in ctx.phase_kernel("join-probe") else 224,
+                      "attempts": ctx.get_counter("join_attempts"), "probe_kernel": ctx.phase_kernel("join-probe"), "stats": stats, "phase_ms": tm}))
 
 
 if __name__ == "__main__":
