@@ -592,106 +592,142 @@ struct Part12 {
   uint32_t cap;
 };
 
-__global__ __launch_bounds__(k64Block) void k64_probe12(Part12 RV, Part12 LV, uint32_t nparts, uint64_t* out_fk, uint32_t* out_y, uint32_t* out_x,
+__global__ __launch_bounds__(k64Block) __attribute__((amdgpu_waves_per_eu(6, 6))) void k64_probe12(Part12 RV, Part12 LV, uint32_t nparts, uint64_t* out_fk, uint32_t* out_y, uint32_t* out_x,
                                                          unsigned long long* counters, uint32_t* miss_bits, ProbeSlices slices) {
   __shared__ unsigned long long s_keys[k64Slots];
   __shared__ uint32_t s_vals[k64Slots];
   __shared__ uint32_t s_sp[2];  // the one key equal to the empty marker: {present, value}
   uint32_t my_miss = 0, my_dup = 0;
   uint64_t my_max = 0;
-  constexpr int kU = 4;  // tuples in flight per thread
-  auto body = [&](const uint32_t p, const uint32_t slice) {
-    const uint32_t n_r = RV.cnt[p], n_l = LV.cnt[p];
-    if (n_r > my_max) my_max = n_r;
-    if (n_l == 0) return;
-    if (n_r > k64TableCap) {
-      if (threadIdx.x == 0 && slice == 0) atomicAdd(&counters[2], 1ull);
-      return;
-    }
-    const uint32_t lb = slice * kProbeSlice, le = slices.count ? min(n_l, lb + kProbeSlice) : n_l;  // partition-relative
-    if (lb >= le) return;
-    for (uint32_t i = threadIdx.x; i < k64Slots; i += k64Block) s_keys[i] = k64Empty;
-    if (threadIdx.x == 0) s_sp[0] = 0;
-    __syncthreads();
-    const Tuple12* R = RV.t + (uint64_t)p * RV.cap;
-    for (uint32_t base = 0; base < n_r; base += k64Block * kU) {  // build: table[pk] = x
-      Tuple12 v[kU];
-#pragma unroll
-      for (int u = 0; u < kU; ++u) {
-        const uint32_t i = base + u * k64Block + threadIdx.x;
-        v[u] = Tuple12{0u, 0u, 0u};
-        if (i < n_r) v[u] = gload_tuple12(R + i);
+  // A partition is small (2048 + 2048 tuples on average): its three phases -- clear, build, probe -- are latency chains, so the
+  // loads run AHEAD of them: the build tuples of the next work item are requested before the probe of the current one, its
+  // sizes one phase earlier still, and the first probe tuples before the barrier that completes the table.
+  constexpr int kU = 6;                              // tuples per thread and chunk: one chunk holds any build side the table admits
+  constexpr uint32_t kChunk = kU * k64Block;
+  static_assert(kChunk >= k64TableCap, "a build side is one chunk");
+  const uint32_t n_extra = slices.count ? min(*slices.count, slices.capacity) : 0u;
+  const uint32_t total = nparts + n_extra;           // work items: the partitions, then the (partition, slice >= 1) pairs
+  struct Item {
+    uint32_t p, slice, n_r, n_l;
+    uint64_t dense;
+  };
+  auto fetch = [&](uint32_t w) -> Item {
+    Item it{0u, 0u, 0u, 0u, 0ull};
+    if (w < total) {
+      if (w < nparts) {
+        it.p = w;
+      } else {
+        const uint2 e = slices.list[w - nparts];
+        it.p = e.x;
+        it.slice = e.y;
       }
+      it.n_r = RV.cnt[it.p];
+      it.n_l = LV.cnt[it.p];
+      it.dense = LV.dense[it.p];
+    }
+    return it;
+  };
+  // probe rows [lb, le) of the item's partition; nothing to do: lb >= le
+  auto range = [&](const Item& it, uint32_t& lb, uint32_t& le) {
+    lb = it.slice * kProbeSlice;
+    le = slices.count ? min(it.n_l, lb + kProbeSlice) : it.n_l;
+    if (it.n_r > k64TableCap) le = lb;  // (reported where the item is handled)
+  };
+  auto load_chunk = [&](const Tuple12* base, uint32_t lo, uint32_t hi, Tuple12 (&v)[kU]) {
 #pragma unroll
-      for (int u = 0; u < kU; ++u) {
-        if (base + u * k64Block + threadIdx.x >= n_r) continue;
-        const unsigned long long k = ((unsigned long long)v[u].hi << 32) | v[u].lo;
+    for (int u = 0; u < kU; ++u) {
+      const uint32_t i = lo + u * k64Block + threadIdx.x;
+      v[u] = Tuple12{0u, 0u, 0u};
+      if (i < hi) v[u] = gload_tuple12(base + i);
+    }
+  };
+  Tuple12 Rv[kU], Lv[kU];
+  Item cur = fetch(blockIdx.x);
+  {
+    uint32_t lb, le;
+    range(cur, lb, le);
+    if (lb < le) load_chunk(RV.t + (uint64_t)cur.p * RV.cap, 0u, cur.n_r, Rv);
+  }
+  for (uint32_t w = blockIdx.x; w < total; w += gridDim.x) {
+    const Item nxt = fetch(w + gridDim.x);  // (its sizes arrive while this item's table is built)
+    uint32_t lb, le;
+    range(cur, lb, le);
+    if (cur.n_r > my_max) my_max = cur.n_r;
+    if (cur.n_r > k64TableCap && cur.n_l && threadIdx.x == 0 && cur.slice == 0) atomicAdd(&counters[2], 1ull);
+    const bool work = lb < le;
+    const Tuple12* L = LV.t + (uint64_t)cur.p * LV.cap;
+    if (work) {
+      for (uint32_t i = threadIdx.x; i < k64Slots; i += k64Block) s_keys[i] = k64Empty;
+      if (threadIdx.x == 0) s_sp[0] = 0;
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {  // build: table[pk] = x
+        if (u * k64Block + threadIdx.x >= cur.n_r) continue;
+        const unsigned long long k = ((unsigned long long)Rv[u].hi << 32) | Rv[u].lo;
         if (k == k64Empty) {
-          s_sp[1] = v[u].pay;
-          if (atomicExch(&s_sp[0], 1u) && slice == 0) ++my_dup;
+          s_sp[1] = Rv[u].pay;
+          if (atomicExch(&s_sp[0], 1u) && cur.slice == 0) ++my_dup;
           continue;
         }
         uint32_t slot = ht_hash64(k) & (k64Slots - 1);  // hashtable.c:99-101
         for (uint32_t step = 0; step < k64Slots; ++step) {
           const unsigned long long old = atomicCAS(&s_keys[slot], k64Empty, k);
           if (old == k64Empty || old == k) {  // free cell, or an equal key overwrites (hashtable.c:133)
-            s_vals[slot] = v[u].pay;
-            if (old == k && slice == 0) ++my_dup;
+            s_vals[slot] = Rv[u].pay;
+            if (old == k && cur.slice == 0) ++my_dup;
             break;
           }
           slot = (slot + 1) & (k64Slots - 1);
         }
       }
+      load_chunk(L, lb, le, Lv);
+      __syncthreads();
     }
-    __syncthreads();
-    const Tuple12* L = LV.t + (uint64_t)p * LV.cap;
-    const uint64_t dense = LV.dense[p];
-    for (uint32_t base = lb; base < le; base += k64Block * kU) {  // probe + take of the right payload
-      Tuple12 v[kU];
+    {  // the next item's build side
+      uint32_t nlb, nle;
+      range(nxt, nlb, nle);
+      if (nlb < nle) load_chunk(RV.t + (uint64_t)nxt.p * RV.cap, 0u, nxt.n_r, Rv);
+    }
+    if (work) {
+      for (uint32_t base = lb; base < le; base += kChunk) {  // probe + take of the right payload
+        if (base != lb) load_chunk(L, base, le, Lv);
 #pragma unroll
-      for (int u = 0; u < kU; ++u) {
-        const uint32_t i = base + u * k64Block + threadIdx.x;
-        v[u] = Tuple12{0u, 0u, 0u};
-        if (i < le) v[u] = gload_tuple12(L + i);
-      }
-#pragma unroll
-      for (int u = 0; u < kU; ++u) {
-        const uint32_t i = base + u * k64Block + threadIdx.x;
-        if (i >= le) continue;
-        const unsigned long long k = ((unsigned long long)v[u].hi << 32) | v[u].lo;
-        uint32_t xv = 0;
-        bool hit = false;
-        if (k == k64Empty) {
-          hit = s_sp[0] != 0;
-          xv = s_sp[1];
-        } else {
-          uint32_t slot = ht_hash64(k) & (k64Slots - 1);
-          for (uint32_t step = 0; step < k64Slots; ++step) {
-            const unsigned long long kk = s_keys[slot];
-            if (kk == k) {
-              xv = s_vals[slot];
-              hit = true;
-              break;
+        for (int u = 0; u < kU; ++u) {
+          const uint32_t i = base + u * k64Block + threadIdx.x;
+          if (i >= le) continue;
+          const unsigned long long k = ((unsigned long long)Lv[u].hi << 32) | Lv[u].lo;
+          uint32_t xv = 0;
+          bool hit = false;
+          if (k == k64Empty) {
+            hit = s_sp[0] != 0;
+            xv = s_sp[1];
+          } else {
+            uint32_t slot = ht_hash64(k) & (k64Slots - 1);
+            for (uint32_t step = 0; step < k64Slots; ++step) {
+              const unsigned long long kk = s_keys[slot];
+              if (kk == k) {
+                xv = s_vals[slot];
+                hit = true;
+                break;
+              }
+              if (kk == k64Empty) break;
+              slot = (slot + 1) & (k64Slots - 1);
             }
-            if (kk == k64Empty) break;
-            slot = (slot + 1) & (k64Slots - 1);
           }
+          const uint64_t o = cur.dense + i;
+          if (!hit) {
+            ++my_miss;
+            if (miss_bits) atomicOr(&miss_bits[o >> 5], 1u << (o & 31));
+          }
+          out_fk[o] = k;
+          out_y[o] = Lv[u].pay;
+          out_x[o] = xv;
         }
-        const uint64_t o = dense + i;
-        if (!hit) {
-          ++my_miss;
-          if (miss_bits) atomicOr(&miss_bits[o >> 5], 1u << (o & 31));
-        }
-        out_fk[o] = k;
-        out_y[o] = v[u].pay;
-        out_x[o] = xv;
       }
+      __syncthreads();
     }
-    __syncthreads();
-  };
-  for (uint32_t p = blockIdx.x; p < nparts; p += gridDim.x) body(p, 0u);
-  const uint32_t n_extra = slices.count ? min(*slices.count, slices.capacity) : 0u;
-  for (uint32_t w = blockIdx.x; w < n_extra; w += gridDim.x) body(slices.list[w].x, slices.list[w].y);
+    cur = nxt;
+  }
   const uint64_t wm = wave_reduce_add((uint64_t)my_miss), wd = wave_reduce_add((uint64_t)my_dup);
   if (lane_id() == 0) {
     if (wm) atomicAdd(&counters[0], (unsigned long long)wm);
