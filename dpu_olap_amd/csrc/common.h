@@ -105,6 +105,7 @@ struct olap_ctx {
   int claim_lean = 1;      // claiming pass from columns: the kernel of ring_claim.h (0: ring_scatter.h's)
   int pack6_hash = 1;      // ... and the claiming pass in front of it leaves wang_hash(key) in place of the key (one hash per tuple less)
   int join64_ring = 1;     // olap_join_u64: the histogram-free plan on 12-byte tuples (ring64.h): 0 never, 1 automatic, 2 every two-pass plan of 4..9 bits per pass
+  int join64_tpt = 8;      // ... tuples per producer thread and tile of its passes of <= 256 buckets (8 | 4; 512 buckets always take 4)
   int ring6_tpt = 8;       // packed last pass: tuples per producer thread and tile (8: 4096-tuple tiles flushed at once; 4: 2048-tuple tiles, the flush one tile behind the insert)
   int probe6_geometry = 0; // packed probe: 0 two workgroups of 512 per CU, 1 one workgroup of 1024
   int ring_tpt = 8;        // tuples per producer thread and tile of the ring scatter (8: 4096-tuple tiles, 4: 2048)

@@ -1114,6 +1114,11 @@ int olap_set_tuning(olap_ctx* ctx, const char* key, int value) {
     ctx->join64_ring = value;
     return OLAP_OK;
   }
+  if (!std::strcmp(key, "join64_tpt")) {
+    if (value != 4 && value != 8) return ctx->fail(OLAP_ERR_INVALID, "join64_tpt must be 4 or 8");
+    ctx->join64_tpt = value;
+    return OLAP_OK;
+  }
   if (!std::strcmp(key, "ring6_tpt")) {
     if (value != 4 && value != 8) return ctx->fail(OLAP_ERR_INVALID, "ring6_tpt must be 4 or 8");
     ctx->ring6_tpt = value;

@@ -106,7 +106,12 @@ static int partition_side64(olap_ctx* ctx, const ColumnSet& cs, bool has_payload
 
 // ---- the histogram-free plan (ring64.h): two ring-scatter passes on 12-byte tuples, capacity-layout probe
 using K64RingCfg = Ring64Cfg<kRingFmax, kRingBlock, kRingProd>;
-constexpr int k64RingTpt = 4;  // 2048-tuple tiles: a 256-byte ring (512 buckets) holds 21 tuples, a tile brings 4 on average
+// Tuples per producer thread and tile: 4 (2048-tuple tiles) at 512 buckets -- a 256-byte ring holds 21 tuples, such a tile brings
+// 4 on average -- and 8 (4096-tuple tiles) up to 256 buckets (rings of >= 42 tuples, 16 per tile).  join64_tpt = 4 / 8 overrides.
+static int ring64_tpt(const olap_ctx* ctx, uint32_t fbits) {
+  if (fbits > 8) return 4;
+  return ctx->join64_tpt == 4 ? 4 : 8;
+}
 
 // Region size of pass 0 (tuples, a multiple of the allotment): the average bucket, 8 sigma (uniform hash) and the allotments the
 // workgroups may leave unused -- per workgroup and bucket the one in use, the reserve and a claim in flight.  0: does not fit.
@@ -159,8 +164,10 @@ static int partition_side64_ring(olap_ctx* ctx, const ColumnSet& cs, bool has_pa
   so->t = (const Tuple12*)fin;
   if (!cursor || !seg_total || !so->cnt || !so->dense || !cap0) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (64-bit ring passes)");
   OLAP_HIP(ctx, hipMemsetAsync(cursor, 0, F0 * 4, ctx->stream));
-  auto claim_kernel = k64_ring<true, kRingFmax, kRingBlock, kRingProd, k64RingTpt>;
-  auto cap_kernel = k64_ring<false, kRingFmax, kRingBlock, kRingProd, k64RingTpt>;
+  // (the claiming pass gains from the larger tile -- 2^27 tuples 0.89 -> 0.72 ms -- the capacity pass loses: 0.92 -> 1.12 ms)
+  const bool claim8 = ring64_tpt(ctx, b0) == 8, cap8 = false;
+  auto claim_kernel = claim8 ? k64_ring<true, kRingFmax, kRingBlock, kRingProd, 8> : k64_ring<true, kRingFmax, kRingBlock, kRingProd, 4>;
+  auto cap_kernel = cap8 ? k64_ring<false, kRingFmax, kRingBlock, kRingProd, 8> : k64_ring<false, kRingFmax, kRingBlock, kRingProd, 4>;
   OLAP_TRY(allow_lds(ctx, reinterpret_cast<const void*>(claim_kernel), K64RingCfg::kBytes));
   OLAP_TRY(allow_lds(ctx, reinterpret_cast<const void*>(cap_kernel), K64RingCfg::kBytes));
   {  // pass 0: one workgroup per CU, a contiguous run of tiles each
@@ -174,7 +181,7 @@ static int partition_side64_ring(olap_ctx* ctx, const ColumnSet& cs, bool has_pa
     const uint64_t blocks = std::max<uint64_t>(1, (tiles + src.tiles_per_block - 1) / src.tiles_per_block);
     const ClaimOut cq{cap0, cursor, d_overflow, 0u, (uint32_t)F0, 0u};
     PhaseScope ps(ctx, PH_PART_SCATTER_CLAIM);
-    ctx->phase_kernel[PH_PART_SCATTER_CLAIM] = "olap::k64_ring<true, 512, 1024, 8, 4>";
+    ctx->phase_kernel[PH_PART_SCATTER_CLAIM] = claim8 ? "olap::k64_ring<true, 512, 1024, 8, 8>" : "olap::k64_ring<true, 512, 1024, 8, 4>";
     hipLaunchKernelGGL(claim_kernel, dim3((unsigned)blocks), dim3(kRingBlock), K64RingCfg::kBytes, ctx->stream, src, 32u - b0, b0, tmp, CapOut{}, cq);
     OLAP_HIP(ctx, hipGetLastError());
   }
@@ -189,7 +196,7 @@ static int partition_side64_ring(olap_ctx* ctx, const ColumnSet& cs, bool has_pa
     src.blocks_per_seg = 1;
     const CapOut co{cap1, so->cnt, so->dense, d_overflow, seg_total};
     PhaseScope ps(ctx, PH_PART_SCATTER_CAP);
-    ctx->phase_kernel[PH_PART_SCATTER_CAP] = "olap::k64_ring<false, 512, 1024, 8, 4>";
+    ctx->phase_kernel[PH_PART_SCATTER_CAP] = cap8 ? "olap::k64_ring<false, 512, 1024, 8, 8>" : "olap::k64_ring<false, 512, 1024, 8, 4>";
     hipLaunchKernelGGL(cap_kernel, dim3((unsigned)F0), dim3(kRingBlock), K64RingCfg::kBytes, ctx->stream, src, 32u - b0 - b1, b1, fin, co, ClaimOut{});
     OLAP_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_dense_fix, dim3((unsigned)F0), dim3(1024), 0, ctx->stream, (const uint64_t*)seg_total, (uint32_t)F1, so->dense);
@@ -207,6 +214,10 @@ static int join64_once(olap_ctx* ctx, const uint64_t* const* lfk, const uint32_t
   OLAP_TRY(make_plan64(ctx, total_bits, &plan, ring && ctx->join64_ring >= 2 && total_bits >= 8 && total_bits <= (uint32_t)k64MaxFBits ? 2 : 1));
   const uint32_t P = 1u << plan.total_bits;
   ring = ring && ring64_eligible(ctx, NL, NR, plan);
+  if (ring && plan.total_bits == 17) {  // 8 + 9, not 9 + 8: pass 0 keeps 256 buckets (4096-tuple tiles) and still feeds the last pass 256 segments
+    plan.bits[0] = 8;
+    plan.bits[1] = 9;
+  }
   *ring_overflow = false;
   const uint32_t eb[2] = {8, 4};
   const bool l_pay = ly != nullptr, r_pay = rx != nullptr;
@@ -235,7 +246,7 @@ static int join64_once(olap_ctx* ctx, const uint64_t* const* lfk, const uint32_t
   OLAP_TRY(pinned_begin(ctx, (lnb + rnb + 2) * 8 * 8 + (cseg + 1) * 12 + 8192));
   OLAP_TRY(ws_begin(ctx, need));
   ColumnSet lcs, rcs;
-  const uint32_t unit_rows = ring ? (uint32_t)(kRingProd * kWave * k64RingTpt) : (uint32_t)k64Tile;
+  const uint32_t unit_rows = ring ? (uint32_t)(kRingProd * kWave * ring64_tpt(ctx, plan.bits[0])) : (uint32_t)k64Tile;
   OLAP_TRY(build_column_set(ctx, lcols, l_pay ? 2 : 1, eb, lrows, lnb, in_mem, unit_rows, &lcs));
   OLAP_TRY(build_column_set(ctx, rcols, r_pay ? 2 : 1, eb, rrows, rnb, in_mem, unit_rows, &rcs));
   uint4* tmp0 = ring ? (uint4*)ws_alloc(ctx, tmp_bytes) : plan.passes >= 2 ? (uint4*)ws_alloc(ctx, (maxN + 1) * 16) : nullptr;
@@ -377,6 +388,12 @@ extern "C" int olap_join_u64(olap_ctx* ctx, const uint64_t* const* left_fk_ptrs,
                                              : (uint32_t)std::max(1, ceil_log2_u64((NR + k64TargetBuildRows - 1) / k64TargetBuildRows));
   // a small build side must not leave the probe to a handful of workgroups (as in olap_join_u32): >= 512 partitions, one pass
   if (ctx->radix_bits_total < 0 && bits < (uint32_t)k64MaxFBits && NL >= (1ull << 22)) bits = k64MaxFBits;
+  // The histogram-free passes cost the same for one bit more as long as pass 0 keeps 256 buckets (<= 17 bits in all), and a table
+  // at load 0.25 instead of 0.5 shortens the probing chains the probe kernel spends its time in (2^27 rows: 5.38 -> 5.08 ms).
+  if (ctx->radix_bits_total < 0 && ctx->join64_ring && bits >= 8 && bits < 17) {
+    PassPlan finer;
+    if (make_plan64(ctx, bits + 1, &finer, 2) == OLAP_OK && ring64_eligible(ctx, NL, NR, finer)) ++bits;
+  }
   unsigned long long counters[4] = {0, 0, 0, 0};
   uint64_t kept_rows = NL;
   bool ring = true;  // the histogram-free plan where it applies; a region overflow (skew) falls back to the exact layout

@@ -313,6 +313,7 @@ int olap_join_configure(olap_ctx* ctx, int radix_bits_total, int max_bits_per_pa
  *                      scatter from the columns, capacity-layout ring scatter, capacity-layout probe (csrc/ring64.h; default) |
  *                      0 always the exact-layout pipeline (histogram + scan + scatter per pass, 16-byte tuples) | 2 every plan of
  *                      8..18 radix bits (tests)
+ *   join64_tpt         8 its passes of <= 256 buckets run 4096-tuple tiles (default) | 4 2048-tuple tiles, as passes of 512 buckets always do
  *   direct_table       1 direct-address LDS table when <= 14 hash bits remain (default) | 0 probing table
  *   take_variant       0 automatic | 1 never the LDS-window kernel | 3 small gather tiles | 4 window-bucketed path
  *                      for batches whose data buffer is far larger than LDS (an alternative that measured slower)

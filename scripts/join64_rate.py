@@ -20,11 +20,15 @@ def main():
     ap.add_argument("--log2-batch", type=int, default=21)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--ring", type=int, default=1, help="join64_ring tuning: 0 exact-layout pipeline, 1 automatic, 2 forced")
+    ap.add_argument("--tpt", type=int, default=8)
+    ap.add_argument("--bits", type=int, default=-1)
     a = ap.parse_args()
     n, br = 1 << a.log2_rows, 1 << a.log2_batch
     nb = n // br
     ctx = capi.Context(0)
     ctx.set_tuning("join64_ring", a.ring)
+    ctx.set_tuning("join64_tpt", a.tpt)
+    ctx.join_configure(a.bits, 0)
     rng = np.random.default_rng(3)
     odd = np.uint64(0x9E3779B97F4A7C15)
     rows = np.arange(n, dtype=np.uint64)
