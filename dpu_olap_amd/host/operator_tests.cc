@@ -305,6 +305,34 @@ TEST(JoinTest, Int64Keys) {
   for (const auto& name : native->schema()->field_names()) EXPECT_TRUE(native->GetColumnByName(name)->Equals(gpu->GetColumnByName(name)));
 }
 
+TEST(JoinTest, Int64KeysInt64Payloads) {
+  // all-int64 tables ("join over Arrow int64 columns"): 64-bit keys with 64-bit payload columns and a second payload column on
+  // the right -- the join returns selection vectors and the columns are gathered through them (join_dpu.cc:325-363)
+  const int n = 50000;
+  arrow::Int64Builder pkb, fkb, xb, yb;
+  arrow::UInt32Builder zb;
+  auto key = [](int64_t i) { return (i - 25000) * 0x100000001LL + (i % 5); };
+  for (int i = 0; i < n; ++i) {
+    EXPECT_TRUE(pkb.Append(key(i)).ok());
+    EXPECT_TRUE(xb.Append((int64_t)i * 0x1234567890LL - 7).ok());
+    EXPECT_TRUE(zb.Append((uint32_t)(i * 40503u)).ok());
+  }
+  for (int i = 0; i < 2 * n; ++i) {
+    EXPECT_TRUE(fkb.Append(key(((int64_t)i * 17) % n)).ok());
+    EXPECT_TRUE(yb.Append(-(int64_t)i * 0x100000000LL + i).ok());
+  }
+  auto right = RecordBatchOf({"pk", "x", "z"}, {pkb.Finish().ValueOrDie(), xb.Finish().ValueOrDie(), zb.Finish().ValueOrDie()});
+  auto left = RecordBatchOf({"fk", "y"}, {fkb.Finish().ValueOrDie(), yb.Finish().ValueOrDie()});
+  auto dev = Gpu();
+  auto native = SortedBy(Go(join::JoinNative{left->schema(), right->schema(), {left}, {right}}).ValueOrDie(), {"fk", "y"});
+  auto got = Go(join::JoinGpu{*dev, left->schema(), right->schema(), {left}, {right}}).ValueOrDie();
+  EXPECT_EQ(got->num_columns(), 4);
+  EXPECT_TRUE(got->GetColumnByName("x")->type()->Equals(arrow::int64()));
+  auto gpu = SortedBy(got, {"fk", "y"});
+  EXPECT_EQ(gpu->num_rows(), 2 * n);
+  for (const auto& name : native->schema()->field_names()) EXPECT_TRUE(native->GetColumnByName(name)->Equals(gpu->GetColumnByName(name)));
+}
+
 TEST(JoinTest, MissingForeignKeyIsAnError) {
   auto left = RecordBatchOf({"fk", "y"}, {ArrayOf<U32>({1, 77}), ArrayOf<U32>({5, 6})});
   auto right = RecordBatchOf({"pk", "x"}, {ArrayOf<U32>({1, 2, 3}), ArrayOf<U32>({7, 8, 9})});

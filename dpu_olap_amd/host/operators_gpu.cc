@@ -210,38 +210,62 @@ arrow::Result<std::shared_ptr<arrow::Array>> JoinGpu::Gather(const arrow::Record
   return olap::WrapBuffer(field->type(), (int64_t)n, out.buffers[0]);
 }
 
-// 64-bit keys (the reference's HT_64BIT_KEYS table, dpu/shared/hashtable/hashtable.h:13-18): {fk: 64, y: 32} x {pk: 64, x: 32}
-// through olap_join_u64 on rank 0.
+// 64-bit keys (the reference's HT_64BIT_KEYS table, dpu/shared/hashtable/hashtable.h:13-18) through olap_join_u64 on rank 0.
+// {fk: 64, y: 32} x {pk: 64, x: 32}: the payloads travel with their keys.  Any other schema (64-bit payload columns, several
+// columns per side): the join returns selection vectors and every non-key column is gathered through them, as the 32-bit path
+// does -- the reference's hash_probe + take per column (host/join/join_dpu.cc:325-363).
 arrow::Result<std::shared_ptr<arrow::Table>> JoinGpu::Run64(int fk, int pk) {
   auto is32 = [](const arrow::Field& f) { return f.type()->id() == arrow::Type::UINT32 || f.type()->id() == arrow::Type::INT32; };
-  if (left_schema_->num_fields() != 2 || right_schema_->num_fields() != 2 || !is32(*left_schema_->field(1 - fk)) ||
-      !is32(*right_schema_->field(1 - pk)))
-    return arrow::Status::NotImplemented("the 64-bit-key join carries one 32-bit payload column per side");
   auto outer = timers_->Get("outer");
-  const int ly = 1 - fk, rx = 1 - pk;
+  const bool inline_payloads = left_schema_->num_fields() == 2 && right_schema_->num_fields() == 2 && is32(*left_schema_->field(1 - fk)) &&
+                               is32(*right_schema_->field(1 - pk));
   ARROW_ASSIGN_OR_RAISE(ColumnTable lkey, olap::MakeColumnTable(left_batches_, fk));
   ARROW_ASSIGN_OR_RAISE(ColumnTable rkey, olap::MakeColumnTable(right_batches_, pk));
-  ARROW_ASSIGN_OR_RAISE(ColumnTable lpay, olap::MakeColumnTable(left_batches_, ly));
-  ARROW_ASSIGN_OR_RAISE(ColumnTable rpay, olap::MakeColumnTable(right_batches_, rx));
+  ColumnTable lpay, rpay;
+  if (inline_payloads) {
+    ARROW_ASSIGN_OR_RAISE(lpay, olap::MakeColumnTable(left_batches_, 1 - fk));
+    ARROW_ASSIGN_OR_RAISE(rpay, olap::MakeColumnTable(right_batches_, 1 - pk));
+  }
   const uint64_t n_left = lkey.total_rows();
   ARROW_ASSIGN_OR_RAISE(auto okey, olap::AllocateOutputs({n_left}, 8));
   ARROW_ASSIGN_OR_RAISE(auto opay, olap::AllocateOutputs({n_left, n_left}, 4));
   ARROW_RETURN_NOT_OK(system_.Check(olap_join_set_unmatched(system_.ctx(), drop_unmatched_ ? OLAP_UNMATCHED_DROP : OLAP_UNMATCHED_ERROR)));
   uint64_t out_rows = 0;
   const int rc = olap_join_u64(system_.ctx(), reinterpret_cast<const uint64_t* const*>(lkey.ptrs.data()),
-                               reinterpret_cast<const uint32_t* const*>(lpay.ptrs.data()), lkey.rows.data(), lkey.ptrs.size(),
-                               reinterpret_cast<const uint64_t* const*>(rkey.ptrs.data()),
-                               reinterpret_cast<const uint32_t* const*>(rpay.ptrs.data()), rkey.rows.data(), rkey.ptrs.size(), OLAP_MEM_HOST,
-                               static_cast<uint64_t*>(okey.ptrs[0]), static_cast<uint32_t*>(opay.ptrs[0]), static_cast<uint32_t*>(opay.ptrs[1]),
-                               n_left, OLAP_MEM_HOST, &out_rows, &stats_);
+                               inline_payloads ? reinterpret_cast<const uint32_t* const*>(lpay.ptrs.data()) : nullptr, lkey.rows.data(),
+                               lkey.ptrs.size(), reinterpret_cast<const uint64_t* const*>(rkey.ptrs.data()),
+                               inline_payloads ? reinterpret_cast<const uint32_t* const*>(rpay.ptrs.data()) : nullptr, rkey.rows.data(),
+                               rkey.ptrs.size(), OLAP_MEM_HOST, static_cast<uint64_t*>(okey.ptrs[0]), static_cast<uint32_t*>(opay.ptrs[0]),
+                               static_cast<uint32_t*>(opay.ptrs[1]), n_left, OLAP_MEM_HOST, &out_rows, &stats_);
   (void)olap_join_set_unmatched(system_.ctx(), OLAP_UNMATCHED_ERROR);
   ARROW_RETURN_NOT_OK(system_.Check(rc));
-  std::vector<std::shared_ptr<arrow::Array>> columns(3);
-  columns[fk] = olap::WrapBuffer(left_schema_->field(fk)->type(), (int64_t)out_rows, okey.buffers[0]);
-  columns[ly] = olap::WrapBuffer(left_schema_->field(ly)->type(), (int64_t)out_rows, opay.buffers[0]);
-  columns[2] = olap::WrapBuffer(right_schema_->field(rx)->type(), (int64_t)out_rows, opay.buffers[1]);
+  // result schema: the left columns, then every right column but the key (join_dpu.cc:314-363)
   arrow::FieldVector fields = left_schema_->fields();
-  fields.push_back(right_schema_->field(rx));
+  for (int c = 0; c < right_schema_->num_fields(); ++c)
+    if (c != pk) fields.push_back(right_schema_->field(c));
+  std::vector<std::shared_ptr<arrow::Array>> columns;
+  if (inline_payloads) {
+    columns.resize(3);
+    columns[fk] = olap::WrapBuffer(left_schema_->field(fk)->type(), (int64_t)out_rows, okey.buffers[0]);
+    columns[1 - fk] = olap::WrapBuffer(left_schema_->field(1 - fk)->type(), (int64_t)out_rows, opay.buffers[0]);
+    columns[2] = olap::WrapBuffer(right_schema_->field(1 - pk)->type(), (int64_t)out_rows, opay.buffers[1]);
+  } else {
+    const auto* left_ids = static_cast<const uint32_t*>(opay.ptrs[0]);
+    const auto* right_ids = static_cast<const uint32_t*>(opay.ptrs[1]);
+    for (int c = 0; c < left_schema_->num_fields(); ++c) {
+      if (c == fk) {
+        columns.push_back(olap::WrapBuffer(left_schema_->field(fk)->type(), (int64_t)out_rows, okey.buffers[0]));
+      } else {
+        ARROW_ASSIGN_OR_RAISE(auto col, Gather(left_batches_, c, left_schema_->field(c), left_ids, out_rows));
+        columns.push_back(std::move(col));
+      }
+    }
+    for (int c = 0; c < right_schema_->num_fields(); ++c) {
+      if (c == pk) continue;
+      ARROW_ASSIGN_OR_RAISE(auto col, Gather(right_batches_, c, right_schema_->field(c), right_ids, out_rows));
+      columns.push_back(std::move(col));
+    }
+  }
   outer->Stop();
   ARROW_RETURN_NOT_OK(Finish());
   return arrow::Table::Make(arrow::schema(fields), columns);
