@@ -108,6 +108,10 @@ static uint64_t side_scratch_bytes(const olap_ctx* ctx, uint64_t rows, uint64_t 
     n_seg *= F;
   }
   bytes += 2 * align_up(n_seg * 4, 256) + align_up(n_seg * 8, 256);  // capacity-layout tables (+ the packed layout's hash bits)
+  if (pre && plan.passes == 1) {  // ... per chunk when the pass runs chunk by chunk (presplit_sub_eligible)
+    const uint64_t subs = (uint64_t)pre->n_seg * pre->chunks << plan.bits[0];
+    bytes += 2 * align_up(subs * 4, 256) + align_up(subs * 8, 256) + align_up((uint64_t)pre->n_seg * pre->chunks * 8, 256);
+  }
   bytes += align_up((1ull << plan.bits[0]) * 4, 256) + align_up((1ull << plan.bits[0]) * 8, 256);  // claim cursors, segment totals
   return bytes + 4096;
 }
@@ -120,6 +124,8 @@ struct SideOut {
   uint64_t* dense = nullptr; // capacity layout: [P]
   bool packed = false;       // capacity layout of 6-byte tuples (pack6.h)
   uint32_t* top = nullptr;   // packed: [P] hash bits above the table bits
+  uint32_t nsub = 0;         // packed, pre-split input taken chunk by chunk: sub-partitions per partition (PartView::nsub; 0: plain)
+  uint32_t sub_fbits = 0;
 };
 
 // Region size of the capacity layout: the average partition plus the larger of 1/8 and six standard deviations of a
@@ -137,6 +143,63 @@ static uint32_t region_cap(uint64_t rows, uint64_t P) {
 static uint32_t region_cap_side(uint64_t rows, uint64_t P, bool packed) {
   const uint32_t cap = region_cap(rows, P);
   return packed ? (uint32_t)align_up(cap, kPackAlign) : cap;
+}
+
+// Pre-split input (what a rank holds after the all-to-all) whose ONE remaining pass has too few segments for the capacity
+// layout's one workgroup per segment: the pass runs chunk by chunk instead -- one workgroup per (segment, sender) chunk, every chunk
+// a set of F packed sub-partitions of its own (PassSrc::out_by_block) -- and the probe builds a partition's table from the
+// sub-partitions of all of its segment's chunks (k_join_probe_direct6_sub).  No histogram, 6-byte tuples, as in the
+// single-GPU plan.  presplit_sub: 0 never | 1 (default) when the chunks fill the chip | 2 whenever the plan allows (tests).
+static uint64_t max_chunk_rows(const Presplit* pre) {
+  uint64_t m = 0;
+  for (uint64_t k = 0; k < (uint64_t)pre->n_seg * pre->chunks; ++k) m = std::max(m, pre->hi[k] - pre->lo[k]);
+  return m;
+}
+bool ring_ok(const olap_ctx* ctx, uint32_t fbits, int role);
+static bool presplit_sub_plan_ok(const olap_ctx* ctx, const Presplit* lpre, const Presplit* rpre, const PassPlan& plan, uint32_t table_bits,
+                                 bool direct) {
+  if (!ctx->presplit_sub || !lpre || !rpre || plan.passes != 1 || !direct || !ctx->pack6 || !ctx->capacity_mode || ctx->scatter_variant != 0)
+    return false;
+  const uint32_t fbits = plan.bits[0];
+  return fbits >= 4 && ring_ok(ctx, fbits, 2) && table_bits >= 1 && table_bits <= 16 && lpre->n_seg == rpre->n_seg;
+}
+static uint64_t nonempty_chunks(const Presplit* pre) {
+  uint64_t n = 0;
+  for (uint64_t k = 0; k < (uint64_t)pre->n_seg * pre->chunks; ++k) n += pre->hi[k] > pre->lo[k];
+  return n;
+}
+// Too few chunks to give every CU one (a table that travelled in one slice, few senders): every chunk place is cut into k
+// pieces -- chunk places are just tuple ranges.  k = the power of two that brings the non-empty places to two per CU, while a
+// piece still leaves its sub-partitions >= 128 tuples.
+static uint32_t presplit_refine_factor(const olap_ctx* ctx, const Presplit* pre, uint32_t fbits) {
+  const uint64_t ne = std::max<uint64_t>(nonempty_chunks(pre), 1), want = (uint64_t)ctx->compute_units * (uint64_t)std::max(1, ctx->presplit_refine), rows = max_chunk_rows(pre);
+  uint32_t k = 1;
+  while (ne * k < want && k < 16 && ((rows / (2ull * k)) >> fbits) >= 128) k *= 2;
+  return k;
+}
+static void refine_presplit(const Presplit& src, uint32_t k, std::vector<uint64_t>* lo, std::vector<uint64_t>* hi, Presplit* out) {
+  const uint64_t n = (uint64_t)src.n_seg * src.chunks;
+  lo->resize(n * k);
+  hi->resize(n * k);
+  for (uint64_t c = 0; c < n; ++c) {
+    const uint64_t L = src.lo[c], H = src.hi[c];
+    const uint64_t piece = align_up((H - L + k - 1) / k, 2);  // (pieces start on even tuples: 16-byte loads)
+    for (uint32_t j = 0; j < k; ++j) {
+      const uint64_t a = std::min(L + j * piece, H);
+      (*lo)[c * k + j] = a;
+      (*hi)[c * k + j] = std::min(a + piece, H);
+    }
+  }
+  *out = src;
+  out->chunks = src.chunks * k;
+  out->lo = lo->data();
+  out->hi = hi->data();
+}
+// ... and whether the (refined) chunks are worth it: every CU gets one, sub-partitions of a useful size
+static bool presplit_sub_sizes_ok(const olap_ctx* ctx, const Presplit* pre, uint32_t fbits) {
+  if (pre->chunks > (uint32_t)(kSubBlocks * kWave)) return false;  // (the probe holds a partition's sub-partitions one per lane)
+  if (ctx->presplit_sub >= 2) return true;
+  return nonempty_chunks(pre) >= (uint64_t)ctx->compute_units && (max_chunk_rows(pre) >> fbits) >= 128;
 }
 
 // The last pass may skip its histogram (capacity layout) when every workgroup owns whole
@@ -371,7 +434,7 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
                           uint64_t tuple_n, const PassPlan& plan, uint32_t skip_bits, uint2* tmp0, uint2* tmp1,
                           uint2* final_tuples, bool capm, unsigned long long* d_overflow, SideOut* so,
                           const Presplit* pre = nullptr, bool claim = false, const BucketOrder* order = nullptr, bool pack = false,
-                          unsigned long long* d_foreign = nullptr) {
+                          unsigned long long* d_foreign = nullptr, bool sub = false) {
   const uint64_t rows = tuple_in ? tuple_n : cs.view.total_rows;
   PassSrc src{};
   uint64_t n_seg = 1;
@@ -496,6 +559,33 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
       src.blk_range = ranged ? pre_ranges : nullptr;
     }
     if (blocks > 0x7FFFFFFFull) return ctx->fail(OLAP_ERR_INVALID, "partition grid too large");
+    if (sub && pre_ranges && i == 0 && plan.passes == 1) {  // chunk by chunk into packed sub-partitions (presplit_sub_eligible)
+      const uint64_t nchunk = n_seg * pre->chunks;
+      so->cap = region_cap_side(max_chunk_rows(pre), F, true);
+      if (nchunk * F * ((uint64_t)so->cap * 3 / 64) >= (1ull << 32)) return ctx->fail(OLAP_ERR_INVALID, "packed sub-partitions: too many lines");
+      so->packed = true;
+      so->nsub = pre->chunks;
+      so->sub_fbits = fbits;
+      so->top = (uint32_t*)ws_alloc(ctx, nchunk * F * 4);
+      so->cnt = (uint32_t*)ws_alloc(ctx, nchunk * F * 4);
+      so->dense = (uint64_t*)ws_alloc(ctx, nchunk * F * 8);
+      uint64_t* seg_total = (uint64_t*)ws_alloc(ctx, nchunk * 8);
+      if (!so->top || !so->cnt || !so->dense || !seg_total || !d_foreign) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (sub-partition tables)");
+      src.tuples = in_tuples;
+      src.seg_off = seg_in;
+      src.n_seg = (uint32_t)n_seg;
+      src.blocks_per_seg = pre->chunks;
+      src.blk_range = pre_ranges;
+      src.chunk_split = 1;
+      src.blk_first = nullptr;
+      src.out_by_block = 1;
+      PhaseScope ps(ctx, PH_PART_SCATTER_CAP);
+      const CapOut co{so->cap, so->cnt, so->dense, d_overflow, seg_total};
+      OLAP_TRY(launch_ring6(ctx, /*check=*/true, (unsigned)nchunk, src, shift, fbits, out, co, so->top, d_foreign));
+      hipLaunchKernelGGL(k_dense_fix, dim3((unsigned)nchunk), dim3(1024), 0, ctx->stream, (const uint64_t*)seg_total, (uint32_t)F, so->dense);
+      OLAP_HIP(ctx, hipGetLastError());
+      return OLAP_OK;
+    }
     if (claim_pass) {
       const uint32_t ccap = claim_cap(ctx, rows, F);
       const bool weave = ring_claim && ctx->claim_weave && ccap % (1u << kWeaveShift) == 0;
@@ -678,6 +768,21 @@ static int launch_probe6(olap_ctx* ctx, bool rpk, bool lpk, const PartView& rv, 
   return launch_probe6_as<512, 256>(ctx, rpk, lpk, rv, lv, P, table_bits, d_fk, d_y, d_x, pair_ok, d_cnt, miss_bits, slices);
 }
 
+// ... over sub-partitions (pre-split input taken chunk by chunk)
+static int launch_probe6_sub(olap_ctx* ctx, const PartView& rv, const PartView& lv, uint32_t P, uint32_t table_bits, uint32_t* d_fk, uint32_t* d_y,
+                             uint32_t* d_x, uint32_t pair_ok, unsigned long long* d_cnt, uint32_t* miss_bits) {
+  constexpr int BLOCK = 512, CHUNK = 256;
+  constexpr uint32_t kLds = kDSlots * 4 + kDSlots / 8 + (BLOCK / kWave) * CHUNK * 6;
+  uint64_t grid = (uint64_t)ctx->compute_units * 8;
+  if (grid > P) grid = P;
+  ctx->phase_kernel[PH_JOIN_PROBE] = "olap::k_join_probe_direct6_sub<512, 256>";
+  auto kernel = k_join_probe_direct6_sub<BLOCK, CHUNK>;
+  OLAP_TRY(allow_lds(ctx, reinterpret_cast<const void*>(kernel), kLds));
+  hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(BLOCK), kLds, ctx->stream, rv, lv, P, table_bits, d_fk, d_y, d_x, pair_ok, d_cnt, miss_bits);
+  OLAP_HIP(ctx, hipGetLastError());
+  return OLAP_OK;
+}
+
 static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t* out_y, uint32_t* out_x, int out_mem,
                      uint64_t NL, uint64_t NR, uint32_t total_bits, bool allow_capacity, olap_join_stats* st,
                      unsigned long long counters[6], uint64_t* rows_out, hipEvent_t right_ready) {
@@ -714,6 +819,32 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
   // 6-byte tuples from the last pass to the probe (pack6.h); a side that is redone exactly falls back to 8-byte tuples
   const bool pk_ok = !bc && pack6_ok(ctx, plan, table_bits, direct);
   const bool lpack = pk_ok && lcap, rpack = pk_ok && rcap;
+  // pre-split input with one pass left: chunk by chunk into packed sub-partitions (both sides, or neither), the chunk places cut
+  // finer when there are too few of them
+  const Presplit *lpre = in.l_pre, *rpre = in.r_pre;
+  Presplit lref, rref;
+  std::vector<uint64_t> lref_lo, lref_hi, rref_lo, rref_hi;
+  bool sub = !bc && allow_capacity && presplit_sub_plan_ok(ctx, lpre, rpre, plan, table_bits, direct);
+  if (sub) {
+    const uint32_t kl = presplit_refine_factor(ctx, lpre, plan.bits[0]), kr = presplit_refine_factor(ctx, rpre, plan.bits[0]);
+    if (kl > 1) {
+      refine_presplit(*in.l_pre, kl, &lref_lo, &lref_hi, &lref);
+      lpre = &lref;
+    }
+    if (kr > 1) {
+      refine_presplit(*in.r_pre, kr, &rref_lo, &rref_hi, &rref);
+      rpre = &rref;
+    }
+    sub = presplit_sub_sizes_ok(ctx, lpre, plan.bits[0]) && presplit_sub_sizes_ok(ctx, rpre, plan.bits[0]);
+    if (!sub) {
+      lpre = in.l_pre;
+      rpre = in.r_pre;
+    }
+  }
+  auto sub_units = [&](const Presplit* pre, uint64_t rows) -> uint64_t {  // final buffer of a side in 8-byte units
+    const uint64_t regions = ((uint64_t)pre->n_seg * pre->chunks << plan.bits[0]) * region_cap_side(max_chunk_rows(pre), 1ull << plan.bits[0], true);
+    return std::max<uint64_t>((regions * 6 + 7) / 8 + 512, rows);
+  };
   // final buffers in 8-byte units: the (possibly packed) capacity layout, and never less than an exact redo of the side needs
   auto final_units = [&](uint64_t rows, bool cap, bool pack) -> uint64_t {
     if (bc) return 0;
@@ -721,8 +852,8 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
     const uint64_t regions = (uint64_t)P * region_cap_side(rows, P, pack);
     return pack ? std::max<uint64_t>((regions * 6 + 7) / 8 + 512, rows) : regions;  // (+ 4 KiB: the probe's chunks read whole vectors)
   };
-  const uint64_t lt_tuples = final_units(NL, lcap, lpack);
-  const uint64_t rt_tuples = final_units(NR, rcap, rpack);
+  const uint64_t lt_tuples = sub ? sub_units(lpre, NL) : final_units(NL, lcap, lpack);
+  const uint64_t rt_tuples = sub ? sub_units(rpre, NR) : final_units(NR, rcap, rpack);
   if (lpack && (uint64_t)P * region_cap_side(NL, P, true) * 3 / 64 >= (1ull << 32)) return ctx->fail(OLAP_ERR_INVALID, "packed layout: too many lines");
   if (rpack && (uint64_t)P * region_cap_side(NR, P, true) * 3 / 64 >= (1ull << 32)) return ctx->fail(OLAP_ERR_INVALID, "packed layout: too many lines");
   const bool lclaim = !in.l_pre && claim_eligible(ctx, NL, plan, lcap);
@@ -732,12 +863,12 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
   if (rclaim) tmp_tuples = std::max<uint64_t>(tmp_tuples, ((uint64_t)claim_cap(ctx, NR, 1ull << plan.bits[0])) << plan.bits[0]);
   const bool l_pay = ly != nullptr, r_pay = rx != nullptr;  // null payload: the tuple carries its global row index
   uint64_t need = column_set_bytes(lrows, lnb, l_pay ? 2 : 1, eb, in_mem) + column_set_bytes(rrows, rnb, r_pay ? 2 : 1, eb, in_mem) +
-                  side_scratch_bytes(ctx, NL, lnb, plan, in.l_pre) + side_scratch_bytes(ctx, NR, rnb, plan, in.r_pre) +
+                  side_scratch_bytes(ctx, NL, lnb, plan, lpre) + side_scratch_bytes(ctx, NR, rnb, plan, rpre) +
                   align_up((lt_tuples + 2) * 8, 256) + align_up((rt_tuples + 2) * 8, 256) + 8192;
   need += align_up((NL / kProbeSlice + 2) * 8, 256) + 256;  // probe slice list
   need += split_column_set_bytes(lnb, 2) + split_column_set_bytes(rnb, 2);  // piece views of ragged column input
-  if (lcap || lclaim) need += side_scratch_bytes(ctx, NL, lnb, plan, in.l_pre);  // an exact redo of a side whose regions overflowed
-  if (rcap || rclaim) need += side_scratch_bytes(ctx, NR, rnb, plan, in.r_pre);
+  if (lcap || lclaim || sub) need += side_scratch_bytes(ctx, NL, lnb, plan, in.l_pre);  // an exact redo of a side whose regions overflowed
+  if (rcap || rclaim || sub) need += side_scratch_bytes(ctx, NR, rnb, plan, in.r_pre);
   if (plan.passes >= 2) need += align_up((tmp_tuples + 2) * 8, 256);
   if (plan.passes >= 3) need += align_up((maxN + 2) * 8, 256);
   if (out_mem == OLAP_MEM_HOST) need += 3 * align_up(NL * 4 + 4, 256);
@@ -745,7 +876,9 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
   const uint64_t miss_words = (NL + 31) / 32 + 2;
   if (drop) need += align_up(miss_words * 4, 256);
   uint64_t pin = (lnb + rnb + 2) * 8 * 8 + 8192 + split_column_set_pinned(lnb, 2) + split_column_set_pinned(rnb, 2);
-  if (in.l_pre) pin += 2 * ((uint64_t)in.l_pre->n_seg * in.l_pre->chunks * 16 + ((uint64_t)in.l_pre->n_seg + 1) * 8 + 512);
+  if (lpre) pin += 2 * ((uint64_t)lpre->n_seg * lpre->chunks * 16 + ((uint64_t)lpre->n_seg + 1) * 8 + 512) +
+                   2 * ((uint64_t)rpre->n_seg * rpre->chunks * 16 + ((uint64_t)rpre->n_seg + 1) * 8 + 512) +
+                   2 * ((uint64_t)in.l_pre->n_seg * in.l_pre->chunks * 16 + ((uint64_t)in.l_pre->n_seg + 1) * 8 + 512);
   OLAP_TRY(pinned_begin(ctx, pin));
   OLAP_TRY(ws_begin(ctx, need));
   ColumnSet lcs, rcs;
@@ -794,21 +927,22 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
     OLAP_HIP(ctx, hipGetLastError());
   } else {
   OLAP_TRY(partition_side(ctx, lcs, l_pay, in.l_tuples, NL, plan, (uint32_t)ctx->hash_skip_bits, tmp0, tmp1, Lt, lcap,
-                          d_cnt + 4, &lso, in.l_pre, lclaim, nullptr, lpack, d_cnt + 8));
+                          d_cnt + 4, &lso, sub ? lpre : in.l_pre, lclaim, nullptr, lpack, d_cnt + 8, sub));
   if (right_ready) {  // the right table may still be arriving (olap_join_set_right_ready_event)
     OLAP_HIP(ctx, hipStreamWaitEvent(ctx->stream, right_ready, 0));
   }
   OLAP_TRY(partition_side(ctx, rcs, r_pay, in.r_tuples, NR, plan, (uint32_t)ctx->hash_skip_bits, tmp0, tmp1, Rt, rcap,
-                          d_cnt + 6, &rso, in.r_pre, rclaim, nullptr, rpack, d_cnt + 9));
+                          d_cnt + 6, &rso, sub ? rpre : in.r_pre, rclaim, nullptr, rpack, d_cnt + 9, sub));
   // The histogram-free layouts (claimed / fixed-capacity regions) overflow when keys repeat far more than the others: a
   // foreign key with a few hundred rows is enough for its partition's region.  Find out BEFORE the probe, and redo only the
   // side that overflowed, exactly (histogram + scan + scatter into the same buffer) -- the other side's partitions stay.
-  if (lcap || rcap || lclaim || rclaim) {
+  if (lcap || rcap || lclaim || rclaim || sub) {
     unsigned long long* h_over = (unsigned long long*)pinned_alloc(ctx, 32);
     if (!h_over) return ctx->fail(OLAP_ERR_NOMEM, "pinned scratch exhausted");
     OLAP_HIP(ctx, hipMemcpyAsync(h_over, d_cnt + 4, 24, hipMemcpyDeviceToHost, ctx->stream));
     OLAP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const unsigned long long over_l = h_over[0], over_r = h_over[2];
+    unsigned long long over_l = h_over[0], over_r = h_over[2];
+    if (sub && (over_l || over_r)) over_l = over_r = std::max<unsigned long long>(over_l + over_r, 1);  // (the sub-partition probe reads two packed sides: both are redone)
     if (over_l || over_r) {
       ctx->last_join_region_overflows += over_l + over_r;
       ++ctx->last_join_attempts;
@@ -833,14 +967,14 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
     PhaseScope ps(ctx, PH_JOIN_PROBE);
     uint64_t grid = (uint64_t)ctx->compute_units * 8;
     if (grid > P) grid = P;
-    const PartView rv{Rt, rso.off, rso.cnt, rso.dense, rso.cap, rso.top};
-    const PartView lv{Lt, lso.off, lso.cnt, lso.dense, lso.cap, lso.top};
+    const PartView rv{Rt, rso.off, rso.cnt, rso.dense, rso.cap, rso.top, rso.nsub, rso.sub_fbits};
+    const PartView lv{Lt, lso.off, lso.cnt, lso.dense, lso.cap, lso.top, lso.nsub, lso.sub_fbits};
     const uintptr_t a_fk = (uintptr_t)d_fk & 7, a_y = (uintptr_t)d_y & 7, a_x = (uintptr_t)d_x & 7;
     const uint32_t pair_ok = (a_fk | a_y | a_x) == 0 ? 1u : (a_fk == 4 && a_y == 4 && a_x == 4) ? 2u : 0u;
     ctx->phase_kernel[PH_JOIN_PROBE] = direct ? "olap::k_join_probe_direct" : "olap::k_join_probe";
     // probe partitions longer than one slice (skew: a hot foreign key) become several work items
     ProbeSlices slices{nullptr, nullptr, 0};
-    if (ctx->probe_slices) {
+    if (ctx->probe_slices && !lso.nsub) {
       slices.capacity = (uint32_t)std::min<uint64_t>(NL / kProbeSlice + 1, 0xFFFFFFFFull);
       slices.list = (uint2*)ws_alloc(ctx, (uint64_t)slices.capacity * 8);
       slices.count = (uint32_t*)ws_alloc(ctx, 16);
@@ -848,7 +982,9 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
       OLAP_HIP(ctx, hipMemsetAsync(slices.count, 0, 16, ctx->stream));
       hipLaunchKernelGGL(k_probe_slices, dim3((P + 255) / 256), dim3(256), 0, ctx->stream, lv, P, slices);
     }
-    if (direct && (rso.packed || lso.packed)) {
+    if (direct && rso.packed && lso.packed && (rso.nsub || lso.nsub)) {
+      OLAP_TRY(launch_probe6_sub(ctx, rv, lv, P, table_bits, d_fk, d_y, d_x, pair_ok, d_cnt, miss_bits));
+    } else if (direct && (rso.packed || lso.packed)) {
       OLAP_TRY(launch_probe6(ctx, rso.packed, lso.packed, rv, lv, P, table_bits, d_fk, d_y, d_x, pair_ok, d_cnt, miss_bits, slices));
     } else if (direct) {
       uint64_t dgrid = (uint64_t)ctx->compute_units * 8;
@@ -1107,6 +1243,16 @@ int olap_set_tuning(olap_ctx* ctx, const char* key, int value) {
   }
   if (!std::strcmp(key, "pack6_hash")) {
     ctx->pack6_hash = value != 0;
+    return OLAP_OK;
+  }
+  if (!std::strcmp(key, "presplit_refine")) {
+    if (value < 1 || value > 8) return ctx->fail(OLAP_ERR_INVALID, "presplit_refine must be in [1, 8]");
+    ctx->presplit_refine = value;
+    return OLAP_OK;
+  }
+  if (!std::strcmp(key, "presplit_sub")) {
+    if (value < 0 || value > 2) return ctx->fail(OLAP_ERR_INVALID, "presplit_sub must be 0, 1 or 2");
+    ctx->presplit_sub = value;
     return OLAP_OK;
   }
   if (!std::strcmp(key, "join64_ring")) {

@@ -99,6 +99,7 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring6(PassSrc s, uint32_
   const uint32_t RB = 1u << rsh, M = RB - 1u;
   const uint32_t nd = F >= 16u ? F >> 4 : 1u;           // dummy rings
   const TileRange r = block_tiles<SRC_TUPLES, TILE>(s);
+  const uint32_t oseg = s.out_by_block ? blockIdx.x : r.seg;  // what the output regions are numbered by (PassSrc::out_by_block)
   const unsigned lane = lane_id();
   const unsigned wave = threadIdx.x / kWave;
   const uint32_t cap_l = co.cap * 3u / 64u;  // lines per region (cap is a multiple of 64 tuples; the host keeps P * cap_l below 2^32)
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring6(PassSrc s, uint32_
               if (q < RB) continue;  // already in the ring (flushed with it)
               const uint16_t val = hw_of(c.p[i], c.bk[i], j);
               if (q < full) {  // straight to the range the owner reserved (dropped when the region is full)
-                if (info.x != kRingNone) gstore_t(out + (((uint64_t)r.seg * F + b) * cap_l * LB + info.x + (q - RB)) / 2u, val);
+                if (info.x != kRingNone) gstore_t(out + (((uint64_t)oseg * F + b) * cap_l * LB + info.x + (q - RB)) / 2u, val);
               } else {         // tail of the tile: the bucket's new residue
                 *(uint16_t*)(rings + (bs | ((hd + (q - full)) & M))) = val;
               }
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring6(PassSrc s, uint32_
     const uint32_t bpw = F >= (uint32_t)kNF ? F / kNF : 1u;  // buckets per flusher wave: consecutive buckets, consecutive lanes
     const uint32_t b_own = fw * bpw + lane;
     const bool owner = lane < bpw && b_own < F;
-    const uint32_t p_own = r.seg * F + b_own;
+    const uint32_t p_own = oseg * F + b_own;
     const uint32_t line0 = p_own * cap_l;                    // the region's first line
     const uint32_t ring_own = C::kRing + (b_own << rsh);     // LDS address of the bucket's ring
     uint2* list = (uint2*)(smem + C::kList) + fw * C::kListPerWave;
@@ -422,14 +423,14 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring6(PassSrc s, uint32_
 #pragma unroll 1
   for (unsigned w = 0; w < wave; ++w) pre += wtot[w];
   if (t < F) {
-    co.cnt[(uint64_t)r.seg * F + t] = (uint32_t)count;
-    co.dense[(uint64_t)r.seg * F + t] = (co.seg_total ? 0 : r.lo) + pre;
-    ptop[(uint64_t)r.seg * F + t] = segtop == kRingNone ? 0u : ((segtop << fbits) | t);
+    co.cnt[(uint64_t)oseg * F + t] = (uint32_t)count;
+    co.dense[(uint64_t)oseg * F + t] = (co.seg_total ? 0 : r.lo) + pre;
+    ptop[(uint64_t)oseg * F + t] = segtop == kRingNone ? 0u : ((segtop << fbits) | t);
   }
   if (co.seg_total && threadIdx.x == 0) {
     uint64_t total = 0;
     for (int w = 0; w < BLOCK / kWave; ++w) total += wtot[w];
-    co.seg_total[r.seg] = total;
+    co.seg_total[oseg] = total;
   }
 }
 
@@ -474,6 +475,84 @@ __device__ __forceinline__ void scan_packed(const char* region, uint32_t lo, uin
     }
 #pragma unroll
     for (int k = 0; k < LPL; ++k) cur[k] = nxt[k];
+  }
+}
+
+// The same walk over SEVERAL packed regions (the sub-partitions of one partition, PartView::nsub): the chunks of all regions
+// form one sequence that the waves share round-robin, and a wave's next chunk -- of whichever region -- is in flight while it
+// works on the current one, so that short regions (a few chunks each) do not cost a load latency apiece.
+// region(q) -> {base, tuples}: region q as bytes and its length n; f(q, n, i, pay0, h0, pay1, h1): tuples i, i + 1 of region q.
+struct PackedRegion {
+  const char* base;
+  uint32_t n;
+};
+template <int CHUNK, class Region, class Fn>
+__device__ __forceinline__ void scan_packed_multi(uint32_t nregions, Region&& region, char* stage, unsigned wave, unsigned nwaves, unsigned lane,
+                                                  Fn&& f) {
+  static_assert(CHUNK % 128 == 0, "whole pairs per lane");
+  constexpr int NP = CHUNK * 6 / 16;       // 16-byte vectors per chunk
+  constexpr int LPL = (NP + kWave - 1) / kWave;
+  uint4 cur[LPL], nxt[LPL];
+#pragma unroll
+  for (int k = 0; k < LPL; ++k) cur[k] = nxt[k] = make_uint4(0, 0, 0, 0);
+  // this wave's chunks in order: (q, c) = chunk c of region q; `skip` chunks of the shared sequence lie in front of the next one
+  uint32_t q = 0, c0 = 0, skip = wave;
+  PackedRegion rg = nregions ? region(0u) : PackedRegion{nullptr, 0u};
+  uint32_t c1 = (rg.n + CHUNK - 1) / CHUNK;
+  auto advance = [&](uint32_t& oq, uint32_t& oc, const char*& obase, uint32_t& on) -> bool {
+    for (;;) {
+      if (q >= nregions) return false;
+      const uint32_t avail = c1 - c0;
+      if (skip < avail) {
+        oq = q;
+        oc = c0 + skip;
+        obase = rg.base;
+        on = rg.n;
+        c0 = oc + 1;
+        skip = nwaves - 1;
+        return true;
+      }
+      skip -= avail;
+      ++q;
+      c0 = 0;
+      if (q < nregions) {
+        rg = region(q);
+        c1 = (rg.n + CHUNK - 1) / CHUNK;
+      }
+    }
+  };
+  auto load = [&](const char* base, uint32_t cc, uint4 (&v)[LPL]) {
+#pragma unroll
+    for (int k = 0; k < LPL; ++k) {
+      const uint32_t piece = k * kWave + lane;
+      if (NP % kWave == 0 || piece < (uint32_t)NP) v[k] = gload4(base + ((uint64_t)cc * NP + piece) * 16);
+    }
+  };
+  uint32_t cq = 0, cc = 0, cn = 0, nq = 0, nc = 0, nn = 0;
+  const char *cb = nullptr, *nb = nullptr;
+  bool have = advance(cq, cc, cb, cn);
+  if (have) load(cb, cc, cur);
+  while (have) {
+    const bool more = advance(nq, nc, nb, nn);
+    if (more) load(nb, nc, nxt);
+#pragma unroll
+    for (int k = 0; k < LPL; ++k) {
+      const uint32_t piece = k * kWave + lane;
+      if (NP % kWave == 0 || piece < (uint32_t)NP) *(uint4*)(stage + piece * 16) = cur[k];
+    }
+#pragma unroll
+    for (int j = 0; j < CHUNK / 128; ++j) {
+      const uint32_t m = j * kWave + lane;  // pair index inside the chunk
+      const uint32_t* d = (const uint32_t*)(stage + 12 * m);
+      const uint32_t d0 = d[0], d1 = d[1], d2 = d[2];
+      f(cq, cn, cc * CHUNK + 2 * m, d0, d1 & 0xFFFFu, (d1 >> 16) | (d2 << 16), d2 >> 16);
+    }
+#pragma unroll
+    for (int k = 0; k < LPL; ++k) cur[k] = nxt[k];
+    cq = nq;
+    cc = nc;
+    cn = nn;
+    have = more;
   }
 }
 
@@ -662,6 +741,162 @@ __global__ __launch_bounds__(BLOCK) void k_join_probe_direct6(PartView RV, PartV
   for (uint32_t p = blockIdx.x; p < nparts; p += gridDim.x) body(p, 0u);
   const uint32_t n_extra = slices.count ? min(*slices.count, slices.capacity) : 0u;
   for (uint32_t w = blockIdx.x; w < n_extra; w += gridDim.x) body(slices.list[w].x, slices.list[w].y);
+  const uint64_t wm = wave_reduce_add((uint64_t)my_miss);
+  const uint64_t wd = wave_reduce_add((uint64_t)my_dup);
+  const uint64_t wf = wave_reduce_add((uint64_t)my_foreign);
+  if (lane == 0) {
+    if (wm) atomicAdd(&counters[0], (unsigned long long)wm);
+    if (wd) atomicAdd(&counters[1], (unsigned long long)wd);
+    if (wf) atomicAdd(&counters[5], (unsigned long long)wf);
+  }
+  if (threadIdx.x == 0) atomicMax(&counters[3], (unsigned long long)my_max);
+}
+
+// k_join_probe_direct6 over sub-partitions (PartView::nsub; both sides packed): what a rank joins after the all-to-all, when its
+// last pass ran chunk by chunk (one workgroup per (segment, sender) chunk, PassSrc::out_by_block) because the segments alone are
+// too few to fill the chip.  Partition p = (segment j, bucket b): its table is built from the right side's sub-partitions of all
+// chunks of segment j, then the left side's sub-partitions are probed one after the other; result rows are (segment, chunk,
+// bucket)-major.  No probe slices (a skewed side overruns its regions first and is redone with the exact layout).
+constexpr int kSubBlocks = 4;  // sub-partitions per partition: at most kSubBlocks x 64 (the host falls back to the histogram pipeline beyond)
+template <int BLOCK, int CHUNK>
+__global__ __launch_bounds__(BLOCK) void k_join_probe_direct6_sub(PartView RV, PartView LV, uint32_t nparts, uint32_t table_bits, uint32_t* out_fk,
+                                                                    uint32_t* out_y, uint32_t* out_x, uint32_t pair_store_ok,
+                                                                    unsigned long long* counters, uint32_t* miss_bits) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint32_t* s_vals = (uint32_t*)smem;
+  uint32_t* s_used = (uint32_t*)(smem + kDSlots * 4);
+  const unsigned lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  constexpr unsigned kNW = BLOCK / kWave;
+  char* stage = smem + kDSlots * 4 + kDSlots / 8 + wave * (CHUNK * 6);
+  const char* R = (const char*)RV.t;
+  const char* L = (const char*)LV.t;
+  const uint32_t slots = 1u << table_bits, smask = slots - 1;
+  const uint32_t rn = RV.nsub ? RV.nsub : 1u, ln = LV.nsub ? LV.nsub : 1u;
+  uint32_t my_miss = 0, my_dup = 0, my_foreign = 0;
+  uint64_t my_max = 0;
+  for (uint32_t p = blockIdx.x; p < nparts; p += gridDim.x) {
+    const uint32_t rj = p >> RV.sub_fbits, rb = p & ((1u << RV.sub_fbits) - 1u);
+    const uint32_t lj = p >> LV.sub_fbits, lbk = p & ((1u << LV.sub_fbits) - 1u);
+    auto rsub = [&](uint32_t q) { return ((rj * rn + q) << RV.sub_fbits) | rb; };
+    auto lsub = [&](uint32_t q) { return ((lj * ln + q) << LV.sub_fbits) | lbk; };
+    // The sub-partitions' sizes, dense starts and leading hash bits, one sub-partition per LANE (kSubBlocks x 64 of them at most):
+    // a handful of vector loads per partition instead of a chain of scalar ones per sub-partition; a region's figures are then
+    // read back with readlane.  Every non-empty sub-partition of either side must agree on the bits above the table bits.
+    uint32_t cr[kSubBlocks], cl[kSubBlocks], tl[kSubBlocks], tr[kSubBlocks];
+    uint64_t dl[kSubBlocks];
+#pragma unroll
+    for (int k = 0; k < kSubBlocks; ++k) {
+      const uint32_t q = k * kWave + lane;
+      cr[k] = cl[k] = tl[k] = tr[k] = 0;
+      dl[k] = 0;
+      if (k * kWave < (int)rn && q < rn) {
+        const uint32_t sp = rsub(q);
+        cr[k] = RV.cnt[sp];
+        tr[k] = RV.top[sp];
+      }
+      if (k * kWave < (int)ln && q < ln) {
+        const uint32_t sp = lsub(q);
+        cl[k] = LV.cnt[sp];
+        tl[k] = LV.top[sp];
+        dl[k] = LV.dense[sp];
+      }
+    }
+    uint64_t n_r = 0, n_l = 0;
+    uint32_t top = 0;
+    bool have_top = false;
+#pragma unroll
+    for (int k = 0; k < kSubBlocks; ++k) {
+      n_r += wave_reduce_add((uint64_t)cr[k]);
+      n_l += wave_reduce_add((uint64_t)cl[k]);
+      const unsigned long long m = __ballot(cl[k] != 0);
+      if (!have_top && m) {
+        top = __builtin_amdgcn_readlane(tl[k], (int)__builtin_ctzll(m));
+        have_top = true;
+      }
+    }
+    n_r = uniform_u64(n_r);
+    n_l = uniform_u64(n_l);
+    if (n_r > my_max) my_max = n_r;
+    if (n_l == 0) continue;
+    uint64_t bad = 0;
+#pragma unroll
+    for (int k = 0; k < kSubBlocks; ++k)
+      bad += wave_reduce_add((uint64_t)((cl[k] && tl[k] != top) ? cl[k] : 0u) + (uint64_t)((cr[k] && tr[k] != top) ? cr[k] : 0u));
+    if (bad && threadIdx.x == 0) my_foreign += (uint32_t)min(uniform_u64(bad), (uint64_t)0xFFFFFFFFu);
+    auto pick32 = [&](const uint32_t (&v)[kSubBlocks], uint32_t q) -> uint32_t {
+      uint32_t r = __builtin_amdgcn_readlane(v[0], (int)(q & 63u));
+#pragma unroll
+      for (int k = 1; k < kSubBlocks; ++k)
+        if ((q >> 6) == (uint32_t)k) r = __builtin_amdgcn_readlane(v[k], (int)(q & 63u));
+      return r;
+    };
+    auto pick_dense = [&](uint32_t q) -> uint64_t {
+      uint32_t lo32 = __builtin_amdgcn_readlane((uint32_t)dl[0], (int)(q & 63u)), hi32 = __builtin_amdgcn_readlane((uint32_t)(dl[0] >> 32), (int)(q & 63u));
+#pragma unroll
+      for (int k = 1; k < kSubBlocks; ++k)
+        if ((q >> 6) == (uint32_t)k) {
+          lo32 = __builtin_amdgcn_readlane((uint32_t)dl[k], (int)(q & 63u));
+          hi32 = __builtin_amdgcn_readlane((uint32_t)(dl[k] >> 32), (int)(q & 63u));
+        }
+      return ((uint64_t)hi32 << 32) | lo32;
+    };
+    for (uint32_t i = threadIdx.x; i < (slots + 31) / 32; i += BLOCK) s_used[i] = 0;
+    __syncthreads();
+    scan_packed_multi<CHUNK>(
+        rn, [&](uint32_t q) { return PackedRegion{R + (uint64_t)rsub(q) * RV.cap * 6, pick32(cr, q)}; }, stage, wave, kNW, lane,
+        [&](uint32_t, uint32_t n, uint32_t i, uint32_t p0, uint32_t h0, uint32_t p1, uint32_t h1) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            if (i + h >= n) continue;
+            const uint32_t slot = (h ? h1 : h0) & smask;
+            const uint32_t bit = 1u << (slot & 31);
+            if (atomicOr(&s_used[slot >> 5], bit) & bit) ++my_dup;  // equal key overwrites (hashtable.c:133)
+            s_vals[slot] = h ? p1 : p0;
+          }
+        });
+    __syncthreads();
+    const uint32_t top_bits = top << table_bits;
+    scan_packed_multi<CHUNK>(
+        ln,
+        [&](uint32_t q) { return PackedRegion{L + (uint64_t)lsub(q) * LV.cap * 6, pick32(cl, q)}; }, stage, wave, kNW, lane,
+        [&](uint32_t q, uint32_t n, uint32_t i, uint32_t p0, uint32_t h0, uint32_t p1, uint32_t h1) {
+          const uint64_t dense = pick_dense(q);
+          // 8-byte pair stores need an 8-byte aligned element (tuple indices here are even): as k_join_probe_direct
+          const uint32_t pair_store = pair_store_ok && ((dense + (pair_store_ok >> 1)) & 1) == 0;
+          uint32_t xs[2], fk[2];
+          bool ok[2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            ok[h] = i + h < n;
+            const uint32_t slot = (h ? h1 : h0) & smask;
+            fk[h] = wang_hash_inv(top_bits | slot);
+            const bool hit = (s_used[slot >> 5] >> (slot & 31)) & 1u;
+            xs[h] = s_vals[slot];
+            if (ok[h] && !hit) {
+              ++my_miss;
+              if (miss_bits) atomicOr(&miss_bits[(i + h + dense) >> 5], 1u << ((i + h + dense) & 31));  // drop mode: mark the row
+            }
+          }
+          const uint64_t o = i + dense;
+          if (ok[0] && ok[1] && pair_store) {
+            *(uint2*)(out_fk + o) = make_uint2(fk[0], fk[1]);
+            *(uint2*)(out_y + o) = make_uint2(p0, p1);
+            *(uint2*)(out_x + o) = make_uint2(xs[0], xs[1]);
+          } else {
+            if (ok[0]) {
+              out_fk[o] = fk[0];
+              out_y[o] = p0;
+              out_x[o] = xs[0];
+            }
+            if (ok[1]) {
+              out_fk[o + 1] = fk[1];
+              out_y[o + 1] = p1;
+              out_x[o + 1] = xs[1];
+            }
+          }
+        });
+    __syncthreads();
+  }
   const uint64_t wm = wave_reduce_add((uint64_t)my_miss);
   const uint64_t wd = wave_reduce_add((uint64_t)my_dup);
   const uint64_t wf = wave_reduce_add((uint64_t)my_foreign);

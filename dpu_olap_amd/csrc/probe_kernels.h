@@ -22,6 +22,11 @@ struct PartView {
   const uint64_t* dense;
   uint32_t cap;
   const uint32_t* top;  // packed side (pack6.h: t = 6-byte tuples, capacity layout): per partition, the hash bits above the table bits
+  // packed side written chunk by chunk from pre-split input (PassSrc::out_by_block): partition p = (segment j, bucket b) of a
+  // last pass of 2^sub_fbits buckets is the union of nsub sub-partitions, number ((j * nsub + q) << sub_fbits) | b for chunk q of
+  // its segment; cnt / dense / top are indexed by the sub-partition.  nsub <= 1: plain partitions.
+  uint32_t nsub;
+  uint32_t sub_fbits;
 };
 
 // A probe partition far larger than the others (one hot foreign key) would be streamed by ONE workgroup while the rest of

@@ -75,6 +75,10 @@ struct PassSrc {
   // SRC_TUPLES: the tuples hold wang_hash(key) in place of the key (ClaimOut::store_hash of the pass that wrote them; read
   // by k_part_scatter_ring6 only, whose packed output never needs the key itself)
   uint32_t hashed;
+  // k_part_scatter_ring6 over pre-split input (blk_range, one workgroup per chunk): the output regions, counts, dense starts and
+  // leading hash bits are numbered by the CHUNK (blockIdx.x), not by the segment -- every chunk becomes a set of F
+  // sub-partitions of its own, and the probe builds a partition's table from the sub-partitions of all of its segment's chunks
+  uint32_t out_by_block;
 };
 
 // Bucket of a tuple in a pass: the bits [shift, shift + log2 F) of its hash, in the pass's bucket order.

@@ -309,6 +309,11 @@ int olap_join_configure(olap_ctx* ctx, int radix_bits_total, int max_bits_per_pa
  *                      whole-tile loader, as contiguous runs otherwise) | 0 contiguous runs | N round-robin in chunks of N tiles
  *   claim_weave        1 the claiming ring scatter weaves its regions in 64 KiB chunks, so that the lines the chip writes at
  *                      any moment lie within ~32 MiB (address-translation locality; default) | 0 regions one after the other
+ *   presplit_sub       1 olap_join_presplit_u32 with ONE radix pass left and enough chunks to fill the chip: the pass runs chunk by
+ *                      chunk without a histogram (one workgroup per (segment, sender) chunk, 6-byte tuples, every chunk a set of
+ *                      sub-partitions of its own) and the probe builds a partition's table from the sub-partitions of all of its
+ *                      segment's chunks; the rows then come (segment, chunk, bucket)-major (default) | 0 histogram + scan + scatter
+ *                      over the chunks | 2 whenever the plan allows it, whatever the sizes (tests)
  *   join64_ring        1 olap_join_u64: two-pass plans of large inputs run without histograms on 12-byte tuples -- claiming ring
  *                      scatter from the columns, capacity-layout ring scatter, capacity-layout probe (csrc/ring64.h; default) |
  *                      0 always the exact-layout pipeline (histogram + scan + scatter per pass, 16-byte tuples) | 2 every plan of

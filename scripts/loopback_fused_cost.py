@@ -18,6 +18,10 @@ from dpu_olap_amd.dist_join import GpuLocalOps, _chunk_tables
 ROWS = 2 << 20
 NB = int(os.environ.get("NB", "2048"))
 ctx = capi.Context(0)
+for kv in os.environ.get("OLAP_TUNE", "").split(","):   # e.g. OLAP_TUNE=presplit_sub=0,presplit_refine=1
+    if "=" in kv:
+        ctx.set_tuning(kv.split("=")[0], int(kv.split("=")[1]))
+GS = tuple(int(g) for g in os.environ.get("GS", "8,4,2").split(","))
 dev = torch.device("cuda", 0)
 ops = GpuLocalOps(ctx, dev)
 n = NB * ROWS
@@ -27,7 +31,7 @@ ctx.gen_fk_u32(fk.data_ptr(), n, dg.SEED, dg.STREAM_FK, 0, ROWS, ROWS)
 ctx.gen_uniform_u32(y.data_ptr(), n, dg.SEED, dg.STREAM_Y, 0)
 ctx.gen_index_u32(pk.data_ptr(), n, 0)
 ctx.gen_uniform_u32(x.data_ptr(), n, dg.SEED, dg.STREAM_X, 0)
-for G in (8, 4, 2):
+for G in GS:
     S, per, bits = 512 // G, NB // G, G.bit_length() - 1
     parts = {"L": [], "R": []}
     cnts = {"L": [], "R": []}
