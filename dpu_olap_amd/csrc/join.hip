@@ -169,7 +169,7 @@ static uint64_t nonempty_chunks(const Presplit* pre) {
   return n;
 }
 // Too few chunks to give every CU one (a table that travelled in one slice, few senders): every chunk place is cut into k
-// pieces -- chunk places are just tuple ranges.  k = the power of two that brings the non-empty places to two per CU, while a
+// pieces -- chunk places are just tuple ranges.  k = the power of two that brings the non-empty places to one per CU (presplit_refine), while a
 // piece still leaves its sub-partitions >= 128 tuples.
 static uint32_t presplit_refine_factor(const olap_ctx* ctx, const Presplit* pre, uint32_t fbits) {
   const uint64_t ne = std::max<uint64_t>(nonempty_chunks(pre), 1), want = (uint64_t)ctx->compute_units * (uint64_t)std::max(1, ctx->presplit_refine), rows = max_chunk_rows(pre);
@@ -874,7 +874,10 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
   if (out_mem == OLAP_MEM_HOST) need += 3 * align_up(NL * 4 + 4, 256);
   const bool drop = ctx->join_drop_unmatched != 0;
   const uint64_t miss_words = (NL + 31) / 32 + 2;
-  if (drop) need += align_up(miss_words * 4, 256);
+  if (drop) {  // miss bitmap + the row compaction's scratch
+    const uint64_t cseg = (NL + kCompactSeg - 1) / kCompactSeg;
+    need += align_up(miss_words * 4, 256) + align_up(cseg * 4, 256) + align_up((cseg + 1) * 8, 256) + align_up(NL * 4 + 4, 256);
+  }
   uint64_t pin = (lnb + rnb + 2) * 8 * 8 + 8192 + split_column_set_pinned(lnb, 2) + split_column_set_pinned(rnb, 2);
   if (lpre) pin += 2 * ((uint64_t)lpre->n_seg * lpre->chunks * 16 + ((uint64_t)lpre->n_seg + 1) * 8 + 512) +
                    2 * ((uint64_t)rpre->n_seg * rpre->chunks * 16 + ((uint64_t)rpre->n_seg + 1) * 8 + 512) +
@@ -1010,54 +1013,29 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
   const bool sound = counters[2] == 0 && counters[4] == 0;  // no table / region overflow: the rows written are final
   uint64_t kept_rows = NL;
   if (drop && sound && counters[0]) {
-    // inner join: squeeze the marked rows out of the three columns, order preserved
+    // inner join: squeeze the marked rows out of the three columns, order preserved (scratch from the arena)
     const uint64_t n_seg = (NL + kCompactSeg - 1) / kCompactSeg;
-    uint32_t* d_kept = nullptr;
-    uint64_t* d_base = nullptr;
-    uint32_t* d_tmp = nullptr;
+    uint32_t* d_kept = (uint32_t*)ws_alloc(ctx, n_seg * 4);
+    uint64_t* d_base = (uint64_t*)ws_alloc(ctx, (n_seg + 1) * 8);
+    uint32_t* d_tmp = (uint32_t*)ws_alloc(ctx, NL * 4 + 4);
+    if (!d_kept || !d_base || !d_tmp) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (row compaction)");
     std::vector<uint32_t> kept(n_seg);
     std::vector<uint64_t> base(n_seg + 1, 0);
-    int rc = OLAP_OK;
-    do {
-      if (hipMalloc(&d_kept, n_seg * 4) != hipSuccess || hipMalloc(&d_base, n_seg * 8) != hipSuccess) {
-        rc = ctx->fail(OLAP_ERR_NOMEM, "device allocation for the row compaction failed");
-        break;
-      }
-      hipLaunchKernelGGL(k_compact_count, dim3((unsigned)n_seg), dim3(256), 0, ctx->stream, (const uint32_t*)miss_bits, NL, d_kept);
-      if (hipMemcpyAsync(kept.data(), d_kept, n_seg * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-          hipStreamSynchronize(ctx->stream) != hipSuccess) {
-        rc = ctx->fail(OLAP_ERR_DEVICE, "row compaction (count) failed");
-        break;
-      }
-      for (uint64_t k = 0; k < n_seg; ++k) base[k + 1] = base[k] + kept[k];
-      kept_rows = base[n_seg];
-      if (kept_rows + counters[0] != NL) {
-        rc = ctx->fail(OLAP_ERR_DEVICE, "internal: miss bitmap (%llu rows kept) disagrees with the miss counter (%llu of %llu)",
+    hipLaunchKernelGGL(k_compact_count, dim3((unsigned)n_seg), dim3(256), 0, ctx->stream, (const uint32_t*)miss_bits, NL, d_kept);
+    OLAP_HIP(ctx, hipMemcpyAsync(kept.data(), d_kept, n_seg * 4, hipMemcpyDeviceToHost, ctx->stream));
+    OLAP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (uint64_t k = 0; k < n_seg; ++k) base[k + 1] = base[k] + kept[k];
+    kept_rows = base[n_seg];
+    if (kept_rows + counters[0] != NL)
+      return ctx->fail(OLAP_ERR_DEVICE, "internal: miss bitmap (%llu rows kept) disagrees with the miss counter (%llu of %llu)",
                        (unsigned long long)kept_rows, counters[0], (unsigned long long)NL);
-        break;
-      }
-      if (hipMalloc(&d_tmp, kept_rows * 4 + 4) != hipSuccess) {
-        rc = ctx->fail(OLAP_ERR_NOMEM, "device allocation of %llu bytes for the row compaction failed", (unsigned long long)(kept_rows * 4));
-        break;
-      }
-      if (hipMemcpyAsync(d_base, base.data(), n_seg * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
-        rc = ctx->fail(OLAP_ERR_DEVICE, "row compaction (bases) failed");
-        break;
-      }
-      for (uint32_t* col : {d_fk, d_y, d_x}) {
-        hipLaunchKernelGGL(k_compact_rows, dim3((unsigned)n_seg), dim3(256), 0, ctx->stream, (const uint32_t*)col,
-                           (const uint32_t*)miss_bits, (const uint64_t*)d_base, NL, d_tmp);
-        if (hipMemcpyAsync(col, d_tmp, kept_rows * 4, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) {
-          rc = ctx->fail(OLAP_ERR_DEVICE, "row compaction (copy back) failed");
-          break;
-        }
-      }
-      if (rc == OLAP_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = ctx->fail(OLAP_ERR_DEVICE, "row compaction failed");
-    } while (false);
-    (void)hipFree(d_kept);
-    (void)hipFree(d_base);
-    (void)hipFree(d_tmp);
-    if (rc != OLAP_OK) return rc;
+    OLAP_HIP(ctx, hipMemcpyAsync(d_base, base.data(), (n_seg + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    for (uint32_t* col : {d_fk, d_y, d_x}) {
+      hipLaunchKernelGGL(k_compact_rows, dim3((unsigned)n_seg), dim3(256), 0, ctx->stream, (const uint32_t*)col, (const uint32_t*)miss_bits,
+                         (const uint64_t*)d_base, NL, d_tmp);
+      OLAP_HIP(ctx, hipMemcpyAsync(col, d_tmp, kept_rows * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    OLAP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (base lives on this frame)
   }
   if (rows_out) *rows_out = kept_rows;
   if (out_mem == OLAP_MEM_HOST && sound && (counters[0] == 0 || drop) && kept_rows) {

@@ -252,7 +252,9 @@ int olap_split_tuples_u32(olap_ctx* ctx, const uint32_t* const* key_ptrs,
  * array, host tables, one chunk per sender.  The first radix pass reads the chunks in
  * place (one workgroup per chunk), so the exchanged data is not re-grouped first.  This
  * replaces the host-side regrouping of Partitioner::GetOffsets / LoadPartitions
- * (host/partition/partitioner.cc:280-375) for the multi-device case. */
+ * (host/partition/partitioner.cc:280-375) for the multi-device case.  Row order of the result: segment-major; inside a
+ * segment partition-major, or -- when the one remaining pass runs chunk by chunk (tuning knob presplit_sub) -- chunk-major,
+ * then partition-major. */
 int olap_join_presplit_u32(olap_ctx* ctx, const uint64_t* left_tuples, uint64_t n_left,
                            const uint64_t* left_chunk_lo, const uint64_t* left_chunk_hi,
                            const uint64_t* right_tuples, uint64_t n_right,
@@ -314,6 +316,7 @@ int olap_join_configure(olap_ctx* ctx, int radix_bits_total, int max_bits_per_pa
  *                      sub-partitions of its own) and the probe builds a partition's table from the sub-partitions of all of its
  *                      segment's chunks; the rows then come (segment, chunk, bucket)-major (default) | 0 histogram + scan + scatter
  *                      over the chunks | 2 whenever the plan allows it, whatever the sizes (tests)
+ *   presplit_refine    1 ... chunk places are cut into pieces until this many non-empty ones per CU exist (default 1; 1..8)
  *   join64_ring        1 olap_join_u64: two-pass plans of large inputs run without histograms on 12-byte tuples -- claiming ring
  *                      scatter from the columns, capacity-layout ring scatter, capacity-layout probe (csrc/ring64.h; default) |
  *                      0 always the exact-layout pipeline (histogram + scan + scatter per pass, 16-byte tuples) | 2 every plan of

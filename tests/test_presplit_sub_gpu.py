@@ -190,7 +190,7 @@ def test_presplit_sub_inner_join_duplicates_and_skew_fallback(dev):
 def test_presplit_sub_groups_at_sf256_refines_the_chunks(dev):
     """The shape a rank of an 8-GPU job sees, at SF=256 (2^29 rows per side in all), default settings: the tables travel as K = 4
     sub-bucket groups, so a group join holds 16 segments x 8 senders = 128 chunks -- fewer than CUs.  The chunk places are cut
-    into pieces (two per CU), the pass runs chunk by chunk and the sub-partition probe joins them; rank 0's four group joins
+    into pieces (one per CU), the pass runs chunk by chunk and the sub-partition probe joins them; rank 0's four group joins
     must give exactly the rows whose key it owns, x = generator(fk)."""
     import torch
     from dpu_olap_amd import datagen as dg
