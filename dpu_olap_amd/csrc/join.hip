@@ -1223,6 +1223,11 @@ int olap_set_tuning(olap_ctx* ctx, const char* key, int value) {
     ctx->pack6_hash = value != 0;
     return OLAP_OK;
   }
+  if (!std::strcmp(key, "filter_stores")) {
+    if (value < 0 || value > 2) return ctx->fail(OLAP_ERR_INVALID, "filter_stores must be 0, 1 or 2");
+    ctx->filter_stores = value;
+    return OLAP_OK;
+  }
   if (!std::strcmp(key, "presplit_refine")) {
     if (value < 1 || value > 8) return ctx->fail(OLAP_ERR_INVALID, "presplit_refine must be in [1, 8]");
     ctx->presplit_refine = value;

@@ -287,6 +287,138 @@ __global__ __launch_bounds__(kBlock) void k_filter_compact(ColView sv, const voi
   }
 }
 
+// k_filter_compact with the survivors of DENSE tiles (at least half of the rows pass) staged through LDS: they are written, in
+// order, into a 16 KiB strip (ds_write_b32 / b64 per survivor instead of one predicated 4- or 8-byte global store each) and
+// leave as whole 16-byte vectors, lane-contiguous (2^30 rows, all passing: 1.84 -> 1.67 ms; int32 at threshold 2^30 = 75 %:
+// 23.0 -> 21.0 ms per 2^34 rows).  Sparse tiles keep the direct stores and their single barrier (the strip costs a second one:
+// at 25 % it gains nothing, below that it loses 2-3 %).  The output position is kept as (16-byte vector index, elements already in that vector): what does
+// not fill a vector is carried into the next tile, so every vector is written exactly once; only the first vector of a segment
+// that starts inside a vector (its front belongs to the previous segment) and the last, partial one use scalar stores.  Two
+// barriers per tile.  Needs 16-byte aligned output buffers (else: k_filter_compact).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_filter_compact_lds(ColView sv, const void* const* in_ptrs, void* const* out_ptrs, T thr,
+                                                               const uint64_t* seg_base, unsigned long long* out_rows) {
+  constexpr int E = 16 / sizeof(T);
+  constexpr uint32_t TILE = kBlock * kVecPerThread * E;
+  constexpr int NW = kBlock / kWave;
+  using V = typename Vec16<T>::type;
+  __shared__ uint32_t s_tot[2][kVecPerThread][NW];
+  __shared__ __attribute__((aligned(16))) T s_stage[TILE + E];
+  const unsigned lane = lane_id();
+  const unsigned wave = threadIdx.x / kWave;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  int buf = 0;
+  for (uint64_t seg = blockIdx.x; seg < sv.total_units; seg += gridDim.x) {
+    Loc l = locate(sv, seg);
+    const uint64_t rows = batch_rows(sv, l.batch);
+    const uint64_t r0 = l.local_unit * sv.unit_rows;
+    const uint32_t n_seg = (uint32_t)min((uint64_t)sv.unit_rows, rows - r0);
+    const T* in = (const T*)in_ptrs[l.batch] + r0;
+    T* out = (T*)out_ptrs[l.batch];
+    const uint32_t head = min(n_seg, (uint32_t)(((16 - (((uintptr_t)in) & 15)) & 15) / sizeof(T)));  // (as in k_filter_count)
+    const uint64_t base0 = seg_base ? seg_base[seg] : 0;
+    uint64_t vbase = base0 / E * E;           // first element of the vector the next output element falls into
+    uint32_t c = (uint32_t)(base0 - vbase);   // elements of that vector in front of the next output element ...
+    uint32_t foreign = c;                     // ... of which this many are another segment's (never written from here)
+    T carry[E];                               // thread 0: the elements [foreign, c) of the open vector
+#pragma unroll
+    for (int k = 0; k < E; ++k) carry[k] = T(0);
+    for (uint32_t t0 = 0, step = head ? head : TILE; t0 < n_seg; t0 += step, step = TILE) {
+      const uint32_t n = min(step, n_seg - t0);
+      T val[kVecPerThread][E];
+      uint32_t flags[kVecPerThread];
+      filter_tile_flags<T>(in + t0, n, TILE, n == TILE, thr, val, flags);
+      uint32_t rank[kVecPerThread];
+#pragma unroll
+      for (int j = 0; j < kVecPerThread; ++j) {
+        const uint32_t cc = __popc(flags[j]);
+        uint32_t r = 0, tot = 0;
+#pragma unroll
+        for (int bit = 0; bit < 3; ++bit) {  // cc <= 4 -> three bit planes
+          const unsigned long long m = __ballot((cc >> bit) & 1u);
+          r += (uint32_t)__popcll(m & lt_mask) << bit;
+          tot += (uint32_t)__popcll(m) << bit;
+        }
+        rank[j] = r;
+        if (lane == 0) s_tot[buf][j][wave] = tot;
+      }
+      __syncthreads();  // ---- totals known; the previous tile's strip has been read
+      uint32_t tile_total = 0;
+      uint32_t my_off[kVecPerThread];
+#pragma unroll
+      for (int j = 0; j < kVecPerThread; ++j) {
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+          if ((unsigned)w == wave) my_off[j] = tile_total;
+          tile_total += s_tot[buf][j][w];
+        }
+      }
+      if (tile_total * 2u < n) {
+        // Few survivors (selectivity below one half): every survivor its own store, as k_filter_compact -- one barrier for this tile.
+        // The open vector's elements go out first; what this tile writes into the front of the next open vector is then "not ours".
+        if (threadIdx.x == 0) {
+#pragma unroll
+          for (int k = 0; k < E; ++k)
+            if ((uint32_t)k >= foreign && (uint32_t)k < c) gstore_t(out + vbase + k, carry[k]);
+        }
+        const uint64_t base = vbase + c;
+#pragma unroll
+        for (int j = 0; j < kVecPerThread; ++j) {
+          uint64_t o = base + my_off[j] + rank[j];
+#pragma unroll
+          for (int k = 0; k < E; ++k)
+            if (flags[j] & (1u << k)) gstore_t(out + o++, val[j][k]);
+        }
+        const uint64_t nb = base + tile_total;
+        vbase = nb / E * E;
+        c = foreign = (uint32_t)(nb - vbase);
+        buf ^= 1;
+        continue;
+      }
+#pragma unroll
+      for (int j = 0; j < kVecPerThread; ++j) {
+        uint32_t o = c + my_off[j] + rank[j];
+#pragma unroll
+        for (int k = 0; k < E; ++k)
+          if (flags[j] & (1u << k)) s_stage[o++] = val[j][k];
+      }
+      if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < E; ++k)
+          if ((uint32_t)k >= foreign && (uint32_t)k < c) s_stage[k] = carry[k];
+      }
+      __syncthreads();  // ---- the strip holds [foreign, c + tile_total)
+      const uint32_t filled = c + tile_total, nvec = filled / E, rem = filled - nvec * E;
+      for (uint32_t v = threadIdx.x; v < nvec; v += kBlock) {
+        const V x = *(const V*)(s_stage + v * E);
+        if (v == 0 && foreign) {  // this vector's front was written before (another segment's, or a sparse tile's)
+#pragma unroll
+          for (int k = 0; k < E; ++k)
+            if ((uint32_t)k >= foreign) gstore_t(out + vbase + k, vec_get<T>(x, k));
+        } else {
+          gstore_vec16((V*)(out + vbase) + v, x);
+        }
+      }
+      if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < E; ++k)
+          if ((uint32_t)k < rem) carry[k] = s_stage[nvec * E + k];
+      }
+      if (nvec) foreign = 0;
+      vbase += (uint64_t)nvec * E;
+      c = rem;
+      buf ^= 1;
+    }
+    if (threadIdx.x == 0) {  // the open vector's elements
+#pragma unroll
+      for (int k = 0; k < E; ++k)
+        if ((uint32_t)k >= foreign && (uint32_t)k < c) gstore_t(out + vbase + k, carry[k]);
+    }
+    const bool last_seg = (l.local_unit + 1) * (uint64_t)sv.unit_rows >= rows;
+    if (last_seg && threadIdx.x == 0) out_rows[l.batch] = vbase + c;
+  }
+}
+
 // ----------------------------------------------------------------- take
 // Tiles over the index stream of each batch; indices loaded 16 B per lane,
 // values gathered (the batch's data buffer is L2 / Infinity-Cache resident while
@@ -677,8 +809,18 @@ static int run_filter(olap_ctx* ctx, const void* const* ptrs, const uint64_t* ro
         }
       }
       PhaseScope ps(ctx, PH_FILTER_COMPACT);
-      hipLaunchKernelGGL((k_filter_compact<T>), dim3(grid), dim3(kBlock), 0, ctx->stream, cs.view,
-                         cs.dev_ptr_tables[0], (void* const*)d_out_tbl, thr, (const uint64_t*)d_seg_base, d_rows);
+      // Dense tiles through an LDS strip and 16-byte stores (k_filter_compact_lds): for segments of the benchmark's size -- short
+      // batches pay for its longer prologue (1024-row batches: 3.0 -> 3.6 ms per 2^30 rows), and a workgroup that walks a whole
+      // long batch alone is bound by its own latency chain (512 x 2 Mi rows: 1.15 -> 1.24 ms).  Needs 16-byte aligned output buffers.
+      bool lds_stores = ctx->filter_stores >= 2 ||
+                        (ctx->filter_stores == 1 && seg_rows == 16 * TILE && total_rows / cs.view.total_units >= 8 * (uint64_t)TILE);
+      for (uint64_t b = 0; b < cnt && lds_stores; ++b) lds_stores = (((uintptr_t)h_out[b]) & 15) == 0;
+      if (lds_stores)
+        hipLaunchKernelGGL((k_filter_compact_lds<T>), dim3(grid), dim3(kBlock), 0, ctx->stream, cs.view, cs.dev_ptr_tables[0],
+                           (void* const*)d_out_tbl, thr, (const uint64_t*)d_seg_base, d_rows);
+      else
+        hipLaunchKernelGGL((k_filter_compact<T>), dim3(grid), dim3(kBlock), 0, ctx->stream, cs.view,
+                           cs.dev_ptr_tables[0], (void* const*)d_out_tbl, thr, (const uint64_t*)d_seg_base, d_rows);
       OLAP_HIP(ctx, hipGetLastError());
     }
     OLAP_HIP(ctx, hipMemcpyAsync(h_rows, d_rows, (cnt ? cnt : 1) * 8, hipMemcpyDeviceToHost, ctx->stream));

@@ -294,6 +294,9 @@ int olap_join_configure(olap_ctx* ctx, int radix_bits_total, int max_bits_per_pa
  *   ring_tpt           8 (default) | 4 tuples per producer thread and tile of the ring scatter
  *   filter_whole_batches N filter: from N batches per CU on (default 2), a batch longer than 64 Ki rows is still walked by ONE
  *                      workgroup (one pass over the data) | 0 always count + scan + compact over 64 Ki-row segments
+ *   filter_stores      1 filter: tiles in which at least half of the rows pass leave through an LDS strip as whole 16-byte vectors,
+ *                      for segments of >= 32 Ki rows in 16-byte aligned output buffers (default) | 0 every surviving element its own
+ *                      store | 2 the strip for every batch geometry
  *   balance_segments   1 histogram + scatter passes over the segments of an earlier pass give every segment workgroups in
  *                      proportion to its size (a table computed on the device): a segment far larger than the rest -- a hot
  *                      key -- gets its share of the chip (default) | 0 the same number of workgroups for every segment

@@ -10,6 +10,10 @@ import numpy as np  # noqa: E402
 from dpu_olap_amd import capi, datagen as dg  # noqa: E402
 
 ctx = capi.Context(0)
+for kv in os.environ.get("OLAP_TUNE", "").split(","):   # e.g. OLAP_TUNE=filter_stores=1
+    if "=" in kv:
+        ctx.set_tuning(kv.split("=")[0], int(kv.split("=")[1]))
+ONLY = os.environ.get("ONLY", "")
 N = 1 << 30
 
 
