@@ -149,13 +149,23 @@ int build_column_set(olap_ctx* ctx, const void* const* const* cols, int ncols,
   uint64_t* h_unit = (uint64_t*)pinned_alloc(ctx, (nb + 1) * 8);
   uint64_t* h_row = (uint64_t*)pinned_alloc(ctx, (nb + 1) * 8);
   if (!h_unit || !h_row) return ctx->fail(OLAP_ERR_NOMEM, "pinned scratch exhausted");
+  // (hundreds of thousands of batches per call at SF=2048: one division per DISTINCT batch size in a row, not per batch)
   bool uniform = nb > 0;
   h_unit[0] = 0;
   h_row[0] = 0;
+  bool full = nb > 0;
+  uint64_t last_rows = ~0ull, last_units = 0;
+  bool last_whole = false;
   for (uint64_t b = 0; b < nb; ++b) {
-    if (rows[b] != rows[0]) uniform = false;
-    h_row[b + 1] = h_row[b] + rows[b];
-    h_unit[b + 1] = h_unit[b] + (rows[b] + unit_rows - 1) / unit_rows;
+    if (rows[b] != last_rows) {
+      last_rows = rows[b];
+      last_units = (rows[b] + unit_rows - 1) / unit_rows;
+      last_whole = last_units * unit_rows == rows[b];
+      if (b) uniform = false;
+    }
+    full = full && last_whole;
+    h_row[b + 1] = h_row[b] + last_rows;
+    h_unit[b + 1] = h_unit[b] + last_units;
   }
   if (uniform && (rows[0] == 0 || rows[0] > 0xFFFFFFFFull)) uniform = false;
   uint64_t* d_unit = (uint64_t*)ws_alloc(ctx, (nb + 1) * 8);
@@ -177,8 +187,7 @@ int build_column_set(olap_ctx* ctx, const void* const* const* cols, int ncols,
   out->h_rows.assign(rows, rows + nb);
   out->h_elem.assign(elem_bytes, elem_bytes + ncols);
   v.row0 = nullptr;
-  bool full = nb > 0, contiguous = nb > 0;
-  for (uint64_t b = 0; b < nb; ++b) full = full && rows[b] % unit_rows == 0;
+  bool contiguous = nb > 0;
   for (int c = 0; c < ncols; ++c) {
     const void** h_ptrs = (const void**)pinned_alloc(ctx, (nb ? nb : 1) * 8);
     const void** d_ptrs = (const void**)ws_alloc(ctx, (nb ? nb : 1) * 8);
@@ -203,7 +212,7 @@ int build_column_set(olap_ctx* ctx, const void* const* const* cols, int ncols,
       for (uint64_t b = 0; b < nb; ++b) {
         if (rows[b] && !cols[c][b])
           return ctx->fail(OLAP_ERR_INVALID, "null batch pointer (column %d batch %llu)", c, (unsigned long long)b);
-        if (((uintptr_t)cols[c][b]) % elem_bytes[c])
+        if (((uintptr_t)cols[c][b]) & (uintptr_t)(elem_bytes[c] - 1))  // (element sizes are powers of two)
           return ctx->fail(OLAP_ERR_INVALID, "batch pointer not aligned to its element size (column %d batch %llu)", c, (unsigned long long)b);
         h_ptrs[b] = cols[c][b];
       }

@@ -763,7 +763,13 @@ static int run_filter(olap_ctx* ctx, const void* const* ptrs, const uint64_t* ro
     const bool multi_seg = max_rows > seg_rows;
     const void* const* cols[1] = {ptrs + b0};
     uint64_t n_seg_est = 0;
-    for (uint64_t b = b0; b < b1; ++b) n_seg_est += (rows[b] + seg_rows - 1) / seg_rows;
+    for (uint64_t b = b0, last_rows = ~0ull, last_segs = 0; b < b1; ++b) {  // (one division per distinct batch size in a row)
+      if (rows[b] != last_rows) {
+        last_rows = rows[b];
+        last_segs = (rows[b] + seg_rows - 1) / seg_rows;
+      }
+      n_seg_est += last_segs;
+    }
     uint64_t need = column_set_bytes(rows + b0, cnt, 1, &eb, in_mem) + align_up(cnt * 8, 256) * 3 +
                     align_up(n_seg_est * 12, 256) * 2 + 8192;
     if (out_mem == OLAP_MEM_HOST) {
@@ -786,7 +792,7 @@ static int run_filter(olap_ctx* ctx, const void* const* ptrs, const uint64_t* ro
         if (!h_out[b]) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (filter output staging)");
       } else {
         if (rows[b0 + b] && !out_ptrs[b0 + b]) return ctx->fail(OLAP_ERR_INVALID, "null output pointer");
-        if (((uintptr_t)out_ptrs[b0 + b]) % eb) return ctx->fail(OLAP_ERR_INVALID, "output pointer misaligned");
+        if (((uintptr_t)out_ptrs[b0 + b]) & (uintptr_t)(eb - 1)) return ctx->fail(OLAP_ERR_INVALID, "output pointer misaligned");
         h_out[b] = out_ptrs[b0 + b];
       }
     }
@@ -924,7 +930,7 @@ static int run_take(olap_ctx* ctx, const void* const* data_ptrs, const uint64_t*
         if (!h_out[b]) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (take output staging)");
       } else {
         if (idx_rows[b0 + b] && !out_ptrs[b0 + b]) return ctx->fail(OLAP_ERR_INVALID, "null output pointer");
-        if (((uintptr_t)out_ptrs[b0 + b]) % eb) return ctx->fail(OLAP_ERR_INVALID, "output pointer misaligned");
+        if (((uintptr_t)out_ptrs[b0 + b]) & (uintptr_t)(eb - 1)) return ctx->fail(OLAP_ERR_INVALID, "output pointer misaligned");
         h_out[b] = out_ptrs[b0 + b];
       }
     }
