@@ -232,8 +232,9 @@ static int join64_once(olap_ctx* ctx, const uint64_t* const* lfk, const uint32_t
   uint64_t tmp_bytes = 0, lfin_bytes = 0, rfin_bytes = 0;  // ring plan: claimed regions (one side at a time), capacity regions per side
   if (ring) {
     tmp_bytes = align_up((uint64_t)std::max(claim_cap64(ctx, NL, F0), claim_cap64(ctx, NR, F0)) * F0 * k64TupleBytes, 256);
-    lfin_bytes = align_up((uint64_t)region_cap64(NL, P) * P * k64TupleBytes, 256);
-    rfin_bytes = align_up((uint64_t)region_cap64(NR, P) * P * k64TupleBytes, 256);
+    lfin_bytes = align_up((uint64_t)region_cap64(NL, P) * P * k64TupleBytes, 256) + 65536;  // (+ slack: whole 16-byte vectors / tiles are read)
+    rfin_bytes = align_up((uint64_t)region_cap64(NR, P) * P * k64TupleBytes, 256) + 65536;
+    tmp_bytes += 65536;
     need += tmp_bytes + lfin_bytes + rfin_bytes + 2 * side_scratch_bytes64_ring(F0, P);
   } else {
     need += side_scratch_bytes64(ctx, NL, lnb, plan) + side_scratch_bytes64(ctx, NR, rnb, plan) + align_up((NL + 1) * 16, 256) +

@@ -154,6 +154,20 @@ __device__ __forceinline__ void load_tuples12(const PassSrc& s, const TileRange&
   const Tuple12* tv = (const Tuple12*)s.tuples;
   const uint64_t base = r.lo + tile * (uint64_t)TILE;
   t.mask = 0;
+#ifndef OLAP_R64_NO_VEC_LOAD
+  if (TPT == 4 && base + TILE <= r.hi && (base & 3u) == 0) {
+    // a whole tile: thread t takes tuples 4 t .. 4 t + 3 = 48 contiguous, 16-byte aligned bytes as three 16-byte loads
+    // (regions start on 1536-byte boundaries)
+    const uint4* p = (const uint4*)(tv + base) + 3 * threadIdx.x;
+    const uint4 a = gload4(p), b = gload4(p + 1), c = gload4(p + 2);
+    t.lo[0] = a.x; t.hi[0] = a.y; t.p[0] = a.z;
+    t.lo[1] = a.w; t.hi[1] = b.x; t.p[1] = b.y;
+    t.lo[2] = b.z; t.hi[2] = b.w; t.p[2] = c.x;
+    t.lo[3] = c.y; t.hi[3] = c.z; t.p[3] = c.w;
+    t.mask = 0xFu;
+    return;
+  }
+#endif
 #pragma unroll
   for (int j = 0; j < TPT; ++j) {
     const uint64_t i = base + (uint64_t)j * KPROD + threadIdx.x;
