@@ -212,9 +212,10 @@ int olap_join_u32(olap_ctx* ctx, const uint32_t* const* left_fk_ptrs,
  * (dpu/shared/hashtable/hashtable.h:13-18: ht_key_t = uint64_t, values stay uint32_t; hash of a 64-bit key
  * hashtable.c:23-26).  left = {fk: u64, y: u32}, right = {pk: u64, x: u32}, output {fk: u64, y, x}; NULL payload
  * tables give selection vectors as in olap_join_u32.  Same contract (pk unique, every fk matches unless
- * OLAP_UNMATCHED_DROP), same statistics; 16-byte tuples through the radix passes (partition = top bits of
- * wang_hash(hash64(key)), dpu/shared/kernels/partition.c:45-46 applied to the table hash), probing LDS table with
- * 64-bit keys, slot = hash64(key) & (slots - 1) (hashtable.c:99-101). */
+ * OLAP_UNMATCHED_DROP), same statistics; partition = top bits of wang_hash(hash64(key)) (dpu/shared/kernels/partition.c:45-46
+ * applied to the table hash), probing LDS table with 64-bit keys, slot = hash64(key) & (slots - 1) (hashtable.c:99-101).
+ * Large joins (from ~2^26 rows per side) take two histogram-free passes on 12-byte tuples {key, payload} (tuning knob
+ * join64_ring), smaller ones and skewed ones histogram + scan + scatter passes on 16-byte tuples. */
 int olap_join_u64(olap_ctx* ctx, const uint64_t* const* left_fk_ptrs, const uint32_t* const* left_y_ptrs,
                   const uint64_t* left_rows, uint64_t n_left_batches, const uint64_t* const* right_pk_ptrs,
                   const uint32_t* const* right_x_ptrs, const uint64_t* right_rows, uint64_t n_right_batches,
