@@ -335,6 +335,23 @@ static int launch_ring_as(olap_ctx* ctx, unsigned blocks, const PassSrc& src, ui
   return OLAP_OK;
 }
 
+// ring scatter into the EXACT layout of a histogram + scan (4096-tuple tiles: the histogram must have counted the same tiles)
+template <int SRC>
+static int launch_ring_exact_as(olap_ctx* ctx, unsigned blocks, const PassSrc& src, uint32_t shift, uint32_t fbits, const uint32_t* hist,
+                                const uint64_t* seg_out, uint2* out) {
+  constexpr uint32_t kLds = RingCfg<kRingFmax, kRingLine, kRingBlock, kRingProd>::kBytes;
+  auto kernel = k_part_scatter_ring<SRC, false, kRingFmax, kRingLine, kRingBlock, kRingProd, 8, 0, true>;
+  OLAP_TRY(allow_lds(ctx, reinterpret_cast<const void*>(kernel), kLds));
+  ctx->phase_kernel[PH_PART_SCATTER] = SRC == SRC_COLS ? "olap::k_part_scatter_ring<0, false, 512, 16, 1024, 8, 8, 0, true>"
+                                                       : "olap::k_part_scatter_ring<1, false, 512, 16, 1024, 8, 8, 0, true>";
+  CapOut co{};
+  co.hist = hist;
+  co.seg_off = seg_out;
+  hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kRingBlock), kLds, ctx->stream, src, shift, fbits, out, co, ClaimOut{});
+  OLAP_HIP(ctx, hipGetLastError());
+  return OLAP_OK;
+}
+
 // the claiming ring scatter from columns rebuilt around its instruction count (ring_claim.h)
 template <int FULL, bool STOREH>
 static int launch_claim_ring_as(olap_ctx* ctx, unsigned blocks, const PassSrc& src, uint32_t shift, uint32_t fbits, uint2* out, const ClaimOut& cq) {
@@ -421,8 +438,12 @@ static int launch_staged(olap_ctx* ctx, bool cols, unsigned blocks, const PassSr
   return OLAP_OK;
 }
 
-static void launch_hist(olap_ctx* ctx, bool cols, bool g2, unsigned blocks, const PassSrc& src, uint32_t shift, uint32_t fbits, uint32_t* hist) {
-  if (g2 && cols) hipLaunchKernelGGL((k_part_hist<SRC_COLS, kW2Block, kW2Tile>), dim3(blocks), dim3(kW2Block), 0, ctx->stream, src, shift, fbits, hist);
+static void launch_hist(olap_ctx* ctx, bool cols, bool g2, unsigned blocks, const PassSrc& src, uint32_t shift, uint32_t fbits, uint32_t* hist,
+                        bool wide = false) {
+  // wide: geometry 2's tiles counted by 1024-thread workgroups -- the exact ring scatter behind it runs one workgroup per CU
+  if (g2 && wide && cols) hipLaunchKernelGGL((k_part_hist<SRC_COLS, kWBlock, kW2Tile>), dim3(blocks), dim3(kWBlock), 0, ctx->stream, src, shift, fbits, hist);
+  else if (g2 && wide) hipLaunchKernelGGL((k_part_hist<SRC_TUPLES, kWBlock, kW2Tile>), dim3(blocks), dim3(kWBlock), 0, ctx->stream, src, shift, fbits, hist);
+  else if (g2 && cols) hipLaunchKernelGGL((k_part_hist<SRC_COLS, kW2Block, kW2Tile>), dim3(blocks), dim3(kW2Block), 0, ctx->stream, src, shift, fbits, hist);
   else if (g2) hipLaunchKernelGGL((k_part_hist<SRC_TUPLES, kW2Block, kW2Tile>), dim3(blocks), dim3(kW2Block), 0, ctx->stream, src, shift, fbits, hist);
   else if (cols) hipLaunchKernelGGL((k_part_hist<SRC_COLS, kWBlock>), dim3(blocks), dim3(kWBlock), 0, ctx->stream, src, shift, fbits, hist);
   else hipLaunchKernelGGL((k_part_hist<SRC_TUPLES, kWBlock>), dim3(blocks), dim3(kWBlock), 0, ctx->stream, src, shift, fbits, hist);
@@ -506,9 +527,13 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
     const bool claim_pass = claim && i == 0 && plan.passes == 2 && wc && !pre;  // claiming scatter: no histogram
     const bool ring_claim = claim_pass && ring_ok(ctx, fbits, 1);
     const bool ring_cap = capm && i == plan.passes - 1 && !(pre_ranges && i == 0) && ring_ok(ctx, fbits, 2);
+    // the exact layout through the ring scatter (4096-tuple tiles: geometry 2's histogram counts the same tiles); not for chunk
+    // shares of pre-split input (chunk_split), whose histogram runs on other tiles
+    const bool ring_exact = ctx->ring_exact && g2 && !claim_pass && !(capm && i == plan.passes - 1 && !(pre_ranges && i == 0)) &&
+                            ring_ok(ctx, fbits, 3) && fbits >= 1 && (ctx->ring_exact >= 2 || rows >= (1ull << 26));  // (2^25 rows: 0.53 -> 0.58 ms)
     if (cols) {
       const uint64_t tiles = cs.view.total_units;
-      uint64_t nb = (uint64_t)ctx->compute_units * ((ring_claim || (wc && !g2)) ? 1 : 2);
+      uint64_t nb = (uint64_t)ctx->compute_units * ((ring_claim || ring_exact || (wc && !g2)) ? 1 : 2);
       if (nb > tiles) nb = tiles;
       if (nb == 0) nb = 1;
       src.tiles_per_block = (tiles + nb - 1) / nb;
@@ -679,7 +704,7 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
     if (!hist || !seg_out) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (partition pass %d)", i);
     {
       PhaseScope ps(ctx, PH_PART_HIST);
-      launch_hist(ctx, cols, g2, (unsigned)blocks, src, shift, fbits, hist);
+      launch_hist(ctx, cols, g2, (unsigned)blocks, src, shift, fbits, hist, ring_exact && cols);
       OLAP_HIP(ctx, hipGetLastError());
     }
     {
@@ -690,7 +715,10 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
     }
     {
       PhaseScope ps(ctx, PH_PART_SCATTER);
-      if (wc) {
+      if (ring_exact) {
+        if (cols) OLAP_TRY(launch_ring_exact_as<SRC_COLS>(ctx, (unsigned)blocks, src, shift, fbits, hist, seg_out, out));
+        else OLAP_TRY(launch_ring_exact_as<SRC_TUPLES>(ctx, (unsigned)blocks, src, shift, fbits, hist, seg_out, out));
+      } else if (wc) {
         OLAP_TRY((launch_scatter<false>(ctx, cols, g2, fbits <= 9 && ctx->line16, (unsigned)blocks, src, shift, fbits, hist, seg_out,
                                         out, CapOut{})));
       } else {  // tile-staged A/B variant
@@ -1221,6 +1249,11 @@ int olap_set_tuning(olap_ctx* ctx, const char* key, int value) {
   }
   if (!std::strcmp(key, "pack6_hash")) {
     ctx->pack6_hash = value != 0;
+    return OLAP_OK;
+  }
+  if (!std::strcmp(key, "ring_exact")) {
+    if (value < 0 || value > 2) return ctx->fail(OLAP_ERR_INVALID, "ring_exact must be 0, 1 or 2");
+    ctx->ring_exact = value;
     return OLAP_OK;
   }
   if (!std::strcmp(key, "filter_stores")) {

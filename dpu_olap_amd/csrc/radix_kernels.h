@@ -654,6 +654,10 @@ struct CapOut {
   uint64_t* seg_total;  // non-null: the input had fillers, so the segment's dense start is unknown here --
                         // dense[] receives the start inside the segment, seg_total[seg] the segment's
                         // tuple count, and k_dense_fix adds the segment bases afterwards
+  // k_part_scatter_ring<.., EXACT>: the exact layout instead (histogram + scan ran before): workgroup blk writes its tuples of
+  // bucket b from tuple seg_off[seg * F + b] + hist[blk * F + b] on, as k_part_scatter_wc does
+  const uint32_t* hist;
+  const uint64_t* seg_off;
 };
 
 template <int SRC, bool CAPM, int LINE, int BLOCK = kWBlock, int TILE = kPTile>

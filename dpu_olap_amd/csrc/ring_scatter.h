@@ -116,9 +116,15 @@ struct TileRegs<TPT, SRC_COLS, 2> : TileRegsFull<TPT, false> {};
 // SRC: SRC_COLS (pass 0 from the Arrow columns) or SRC_TUPLES.  CLAIM: claimed allotments + fillers
 // (any number of workgroups per output bucket; ClaimOut) instead of the capacity layout (one
 // workgroup per input segment; CapOut).  Tiles of NPROD * 64 * TPT tuples.
-template <int SRC, bool CLAIM, int FMAX, int LINE, int BLOCK, int NPROD, int TPT, int FULL = 0>
+// EXACT (with !CLAIM): the exact layout of a histogram + scan in front (CapOut::hist / seg_off; any number of workgroups per
+// segment, bucket order of pass_bucket) -- what k_part_scatter_wc writes, at the ring scatter's rate.  A workgroup's run of a
+// bucket starts at an arbitrary tuple S: the bucket's ring starts with S mod 16 phantom tuples, so that ring lines and memory
+// lines coincide; the first line (its front belongs to the run before) and the last, partial one leave as 8-byte stores of
+// the owner lane, everything between as whole lines.
+template <int SRC, bool CLAIM, int FMAX, int LINE, int BLOCK, int NPROD, int TPT, int FULL = 0, bool EXACT = false>
 __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring(PassSrc s, uint32_t shift, uint32_t fbits, uint2* out, CapOut co,
                                                                ClaimOut cq) {
+  static_assert(!(EXACT && CLAIM), "the exact layout has no allotments");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using C = RingCfg<FMAX, LINE, BLOCK, NPROD>;
   constexpr int kNF = C::kNF, kProd = C::kProd;
@@ -160,7 +166,9 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring(PassSrc s, uint32_t
   // where tuple p of output region `region` lies (CLAIM: possibly woven regions, radix_kernels.h woven_at)
   const uint32_t wv_shift = CLAIM ? cq.weave_shift : 0u, wv_n = CLAIM ? cq.weave_n : 0u;
   auto at = [&](uint64_t region, uint32_t p) { return woven_at(region, p, cap, wv_shift, wv_n); };
-  for (uint32_t b = threadIdx.x; b < FMAX + C::kDummy; b += BLOCK) cl[b] = 0;
+  // where this workgroup's run of bucket b starts (EXACT)
+  auto run_start = [&](uint32_t b) -> uint64_t { return co.seg_off[(uint64_t)r.seg * F + b] + co.hist[(uint64_t)blockIdx.x * F + b]; };
+  for (uint32_t b = threadIdx.x; b < FMAX + C::kDummy; b += BLOCK) cl[b] = (EXACT && b < F) ? (uint32_t)(run_start(b) & (LINE - 1)) : 0u;
   if (CLAIM) {
     for (uint32_t b = threadIdx.x; b < FMAX; b += BLOCK) {
       rsv[b] = kRingNone;
@@ -181,7 +189,7 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring(PassSrc s, uint32_t
         const uint32_t h = wang_hash(t.key(i));
         // fillers of a claiming producer pass carry another bucket's hash bits (chk_mask 0: none)
         const bool ok = (((t.mask >> i) & 1u) != 0) & (((h >> s.chk_shift) & s.chk_mask) == expect);
-        t.bk[i] = ok ? ((h >> shift) & (F - 1u)) : dummy;
+        t.bk[i] = ok ? (EXACT ? pass_bucket(s, h, shift, F) : ((h >> shift) & (F - 1u))) : dummy;
       }
     };
     ColsCursor cur;
@@ -269,7 +277,12 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring(PassSrc s, uint32_t
             const uint2 info = hot[b];
             const uint32_t full = info.y & 0xFFFFu, hd = info.y >> 16, sl = v[i] & 0xFFFFu;
             if (sl < full) {  // goes straight to the range the owner reserved (dropped when the region is full)
-              if (info.x != kRingNone) gstore2(out + at((uint64_t)r.seg * F + b, info.x + (sl - kRing)), make_uint2(c.key(i), c.pay(i)));
+              if (EXACT) {
+                const uint64_t S = run_start(b);
+                gstore2(out + (S - (S & (LINE - 1))) + info.x + (sl - kRing), make_uint2(c.key(i), c.pay(i)));
+              } else if (info.x != kRingNone) {
+                gstore2(out + at((uint64_t)r.seg * F + b, info.x + (sl - kRing)), make_uint2(c.key(i), c.pay(i)));
+              }
             } else {          // tail of the tile: the bucket's new residue
               ring[b * kRing + ((hd + (sl - full)) & (kRing - 1))] = make_uint2(c.key(i), c.pay(i));
             }
@@ -301,6 +314,15 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring(PassSrc s, uint32_t
     uint32_t fill_lo = 0, fill_hi = 0;           // CLAIM: unused tail of a hot tile's block
     bool dead = !owner;                          // region exhausted (skew): tuples are dropped, *overflow raised
     uint32_t filler = 0;
+    uint64_t xbase = 0;                          // EXACT: the memory line this workgroup's run of the bucket starts in, as a tuple index
+    uint32_t xc0 = 0;                            // ... and the tuples of that line in front of the run (phantoms in the ring)
+    bool first = false;                          // ... the first line has not left yet
+    if (EXACT && owner) {
+      const uint64_t S = run_start(b_own);
+      xc0 = (uint32_t)(S & (LINE - 1));
+      xbase = S - xc0;
+      first = xc0 != 0;
+    }
     if (CLAIM && owner) {
       while (pass_bucket(s, wang_hash(filler), shift, F) == b_own) ++filler;  // a key of another bucket
       const uint32_t got = atomicAdd(&cq.cursor[p_own], 2 * kClaimChunk);
@@ -334,7 +356,7 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring(PassSrc s, uint32_t
       const unsigned long long m = __ballot(has);
       if (!m) return false;
       const uint32_t n = (uint32_t)__popcll(m);
-      if (has) list[__popcll(m & ((1ull << lane) - 1ull))] = make_uint2((uint32_t)(at(p_own, d) / LINE), b_own * kRing + ring_line);  // line index: < 2^32 (cap, chunks: multiples of LINE)
+      if (has) list[__popcll(m & ((1ull << lane) - 1ull))] = make_uint2((uint32_t)((EXACT ? xbase + d : at(p_own, d)) / LINE), b_own * kRing + ring_line);  // line index: < 2^32 (cap, chunks: multiples of LINE)
       __builtin_amdgcn_wave_barrier();
       for (uint32_t k = 0; k < n; k += LPI) {
         const uint32_t j = k + lane / LPL;
@@ -374,6 +396,14 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring(PassSrc s, uint32_t
               pos += LINE;
               rem -= LINE;
             }
+          } else if (EXACT) {
+            if (first) {  // (q == 0, pos == 0) the line's front belongs to the run before: the run's part as 8-byte stores
+              for (uint32_t k = xc0; k < (uint32_t)LINE; ++k) gstore2(out + xbase + k, ring[b_own * kRing + ((hd + k) & (kRing - 1))]);
+              first = false;
+            } else {
+              dq = pos;
+            }
+            pos += LINE;
           } else if ((uint64_t)pos + LINE > cap) {
             dead = true;
             atomicAdd(overflow, 1ull);
@@ -419,7 +449,7 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring(PassSrc s, uint32_t
                   fill_hi = got + blk;
                 }
               }
-            } else if ((uint64_t)pos + nd > cap) {
+            } else if (!EXACT && (uint64_t)pos + nd > cap) {
               dead = true;
               atomicAdd(overflow, 1ull);
             } else {
@@ -470,6 +500,8 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring(PassSrc s, uint32_t
         const uint32_t ahead = rsv[b_own];
         if (ahead != kRingNone && (uint64_t)ahead + kClaimChunk <= cap)
           for (uint32_t q = 0; q < kClaimChunk; q += 2) *(uint4*)(out + at(p_own, ahead + q)) = make_uint4(filler, 0u, filler, 0u);
+      } else if (EXACT) {  // the residue (a first line that never filled still has its phantoms in front)
+        for (uint32_t j = first ? xc0 : 0u; j < rr; ++j) gstore2(out + xbase + pos + j, ring[b_own * kRing + ((hd + j) & (kRing - 1))]);
       } else {
         uint32_t count = pos;
         if (!dead) {
@@ -484,7 +516,7 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring(PassSrc s, uint32_t
       }
     }
   }
-  if (!CLAIM) {  // partition sizes and dense starts (exclusive scan over this segment's buckets, one per thread)
+  if (!CLAIM && !EXACT) {  // partition sizes and dense starts (exclusive scan over this segment's buckets, one per thread)
     __syncthreads();
     const uint32_t t = threadIdx.x;
     const uint64_t count = t < F ? ((const uint32_t*)hot)[t] : 0u;

@@ -292,6 +292,9 @@ int olap_join_configure(olap_ctx* ctx, int radix_bits_total, int max_bits_per_pa
  *   ring_scatter       3 claiming AND capacity passes of <= 512 buckets run the ring scatter: per-bucket LDS rings, 128-byte
  *                      lines, one 1024-thread workgroup per CU (default) | 1 claiming pass only | 2 capacity pass only
  *                      | 0 the write-combining kernels
+ *   ring_exact         1 histogram + scan + scatter passes of <= 512 buckets over >= 2^26 rows scatter through the ring kernel as
+ *                      well, into the exact layout (a run's first and last, partial lines as 8-byte stores; default) | 0 the
+ *                      write-combining kernel | 2 the ring kernel at any size
  *   ring_tpt           8 (default) | 4 tuples per producer thread and tile of the ring scatter
  *   filter_whole_batches N filter: from N batches per CU on (default 2), a batch longer than 64 Ki rows is still walked by ONE
  *                      workgroup (one pass over the data) | 0 always count + scan + compact over 64 Ki-row segments
