@@ -704,11 +704,14 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
     if (!hist || !seg_out) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (partition pass %d)", i);
     {
       PhaseScope ps(ctx, PH_PART_HIST);
+      ctx->phase_kernel[PH_PART_HIST] = g2 ? (ring_exact && cols ? "olap::k_part_hist<0, 1024, 4096>" : cols ? "olap::k_part_hist<0, 512, 4096>" : "olap::k_part_hist<1, 512, 4096>")
+                                           : (cols ? "olap::k_part_hist<0, 1024, 8192>" : "olap::k_part_hist<1, 1024, 8192>");
       launch_hist(ctx, cols, g2, (unsigned)blocks, src, shift, fbits, hist, ring_exact && cols);
       OLAP_HIP(ctx, hipGetLastError());
     }
     {
       PhaseScope ps(ctx, PH_PART_SCAN);
+      ctx->phase_kernel[PH_PART_SCAN] = "olap::k_part_scan";
       hipLaunchKernelGGL(k_part_scan, dim3((unsigned)n_seg), dim3(1024), 0, ctx->stream, hist, seg_in, rows,
                          (uint32_t)n_seg, (uint32_t)bseg, fbits, seg_out, src.blk_first);
       OLAP_HIP(ctx, hipGetLastError());
