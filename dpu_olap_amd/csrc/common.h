@@ -104,6 +104,7 @@ struct olap_ctx {
   int contig_columns = 1;  // pass 0's straight-line loader addresses batches that are slices of one buffer without the pointer tables
   int claim_lean = 1;      // claiming pass from columns: the kernel of ring_claim.h (0: ring_scatter.h's)
   int pack6_hash = 1;      // ... and the claiming pass in front of it leaves wang_hash(key) in place of the key (one hash per tuple less)
+  int ring_exact_blocks = 2; // ... from the columns: workgroups per CU of histogram and scatter (2: two rounds of ring workgroups behind a 512-thread histogram; 1: one round behind a 1024-thread histogram)
   int ring_exact = 1;      // histogram + scan passes of <= 512 buckets over >= 2^26 rows scatter through the ring kernel into the exact layout (0: write-combining kernel, 2: any size)
   int filter_stores = 1;   // filter: 0 every survivor its own store | 1 tiles where most rows pass leave through an LDS strip as 16-byte stores, for segments of >= 32 Ki rows (k_filter_compact_lds) | 2 ... for every shape
   int presplit_refine = 1; // ... its chunk places are cut finer until this many non-empty ones per CU exist (2 measured slower: 7.2 vs 6.6 ms per rank at G=8)

@@ -533,7 +533,7 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
                             ring_ok(ctx, fbits, 3) && fbits >= 1 && (ctx->ring_exact >= 2 || rows >= (1ull << 26));  // (2^25 rows: 0.53 -> 0.58 ms)
     if (cols) {
       const uint64_t tiles = cs.view.total_units;
-      uint64_t nb = (uint64_t)ctx->compute_units * ((ring_claim || ring_exact || (wc && !g2)) ? 1 : 2);
+      uint64_t nb = (uint64_t)ctx->compute_units * ((ring_claim || (ring_exact && ctx->ring_exact_blocks == 1) || (wc && !g2)) ? 1 : 2);
       if (nb > tiles) nb = tiles;
       if (nb == 0) nb = 1;
       src.tiles_per_block = (tiles + nb - 1) / nb;
@@ -704,9 +704,9 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
     if (!hist || !seg_out) return ctx->fail(OLAP_ERR_NOMEM, "workspace exhausted (partition pass %d)", i);
     {
       PhaseScope ps(ctx, PH_PART_HIST);
-      ctx->phase_kernel[PH_PART_HIST] = g2 ? (ring_exact && cols ? "olap::k_part_hist<0, 1024, 4096>" : cols ? "olap::k_part_hist<0, 512, 4096>" : "olap::k_part_hist<1, 512, 4096>")
+      ctx->phase_kernel[PH_PART_HIST] = g2 ? (ring_exact && cols && ctx->ring_exact_blocks == 1 ? "olap::k_part_hist<0, 1024, 4096>" : cols ? "olap::k_part_hist<0, 512, 4096>" : "olap::k_part_hist<1, 512, 4096>")
                                            : (cols ? "olap::k_part_hist<0, 1024, 8192>" : "olap::k_part_hist<1, 1024, 8192>");
-      launch_hist(ctx, cols, g2, (unsigned)blocks, src, shift, fbits, hist, ring_exact && cols);
+      launch_hist(ctx, cols, g2, (unsigned)blocks, src, shift, fbits, hist, ring_exact && cols && ctx->ring_exact_blocks == 1);
       OLAP_HIP(ctx, hipGetLastError());
     }
     {
@@ -1252,6 +1252,11 @@ int olap_set_tuning(olap_ctx* ctx, const char* key, int value) {
   }
   if (!std::strcmp(key, "pack6_hash")) {
     ctx->pack6_hash = value != 0;
+    return OLAP_OK;
+  }
+  if (!std::strcmp(key, "ring_exact_blocks")) {
+    if (value != 1 && value != 2) return ctx->fail(OLAP_ERR_INVALID, "ring_exact_blocks must be 1 or 2");
+    ctx->ring_exact_blocks = value;
     return OLAP_OK;
   }
   if (!std::strcmp(key, "ring_exact")) {
