@@ -137,6 +137,8 @@ def alg_bytes_per_unit(phase, kernel, default):
     side and writes the 12-byte result row."""
     if "k_part_scatter_ring6" in kernel:
         return 8 + 6
+    if "k_join_probe_direct6_pf" in kernel or "k_join_probe_direct6_sub" in kernel:
+        return 6 + 6 + 12
     if "k_join_probe_direct6" in kernel:
         flags = kernel[kernel.index("<") + 1:kernel.rindex(">")].replace(" ", "").split(",")[-2:]
         return sum(6 if f == "true" else 8 for f in flags) + 12

@@ -112,6 +112,7 @@ struct olap_ctx {
   int join64_ring = 1;     // olap_join_u64: the histogram-free plan on 12-byte tuples (ring64.h): 0 never, 1 automatic, 2 every two-pass plan of 4..9 bits per pass
   int join64_tpt = 8;      // ... tuples per producer thread and tile of its passes of <= 256 buckets (8 | 4; 512 buckets always take 4)
   int ring6_tpt = 8;       // packed last pass: tuples per producer thread and tile (8: 4096-tuple tiles flushed at once; 4: 2048-tuple tiles, the flush one tile behind the insert)
+  int probe6_prefetch = 0; // packed probe: the next partition's sizes and first chunks are requested ahead (k_join_probe_direct6_pf)
   int probe6_geometry = 0; // packed probe: 0 two workgroups of 512 per CU, 1 one workgroup of 1024
   int ring_tpt = 8;        // tuples per producer thread and tile of the ring scatter (8: 4096-tuple tiles, 4: 2048)
   int claim_mode = 1;      // pass 0 of a two-pass plan without histogram (claimed allotments): 0 off, 1 auto, 2 always

@@ -791,9 +791,27 @@ static int launch_probe6_as(olap_ctx* ctx, bool rpk, bool lpk, const PartView& r
   return OLAP_OK;
 }
 
+// ... both sides packed, loads ahead of the partition's phases (k_join_probe_direct6_pf)
+static int launch_probe6_pf(olap_ctx* ctx, const PartView& rv, const PartView& lv, uint32_t P, uint32_t table_bits, uint32_t* d_fk, uint32_t* d_y,
+                            uint32_t* d_x, uint32_t pair_ok, unsigned long long* d_cnt, uint32_t* miss_bits, const ProbeSlices& slices) {
+  constexpr int BLOCK = 512, CHUNK = 256;
+  constexpr uint32_t kLds = kDSlots * 4 + kDSlots / 8 + (BLOCK / kWave) * CHUNK * 6;
+  uint64_t grid = (uint64_t)ctx->compute_units * 8;
+  if (grid > P) grid = P;
+  ctx->phase_kernel[PH_JOIN_PROBE] = "olap::k_join_probe_direct6_pf<512, 256>";
+  auto kernel = k_join_probe_direct6_pf<BLOCK, CHUNK>;
+  OLAP_TRY(allow_lds(ctx, reinterpret_cast<const void*>(kernel), kLds));
+  hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(BLOCK), kLds, ctx->stream, rv, lv, P, table_bits, d_fk, d_y, d_x, pair_ok, d_cnt, miss_bits,
+                     slices);
+  OLAP_HIP(ctx, hipGetLastError());
+  return OLAP_OK;
+}
+
 static int launch_probe6(olap_ctx* ctx, bool rpk, bool lpk, const PartView& rv, const PartView& lv, uint32_t P, uint32_t table_bits,
                          uint32_t* d_fk, uint32_t* d_y, uint32_t* d_x, uint32_t pair_ok, unsigned long long* d_cnt, uint32_t* miss_bits,
                          const ProbeSlices& slices) {
+  if (rpk && lpk && ctx->probe6_prefetch && ctx->probe6_geometry != 1)
+    return launch_probe6_pf(ctx, rv, lv, P, table_bits, d_fk, d_y, d_x, pair_ok, d_cnt, miss_bits, slices);
   if (ctx->probe6_geometry == 1)
     return launch_probe6_as<1024, 512>(ctx, rpk, lpk, rv, lv, P, table_bits, d_fk, d_y, d_x, pair_ok, d_cnt, miss_bits, slices);
   return launch_probe6_as<512, 256>(ctx, rpk, lpk, rv, lv, P, table_bits, d_fk, d_y, d_x, pair_ok, d_cnt, miss_bits, slices);
@@ -1252,6 +1270,10 @@ int olap_set_tuning(olap_ctx* ctx, const char* key, int value) {
   }
   if (!std::strcmp(key, "pack6_hash")) {
     ctx->pack6_hash = value != 0;
+    return OLAP_OK;
+  }
+  if (!std::strcmp(key, "probe6_prefetch")) {
+    ctx->probe6_prefetch = value != 0;
     return OLAP_OK;
   }
   if (!std::strcmp(key, "ring_exact_blocks")) {

@@ -440,9 +440,27 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring6(PassSrc s, uint32_
 // strip, out as PAIRS of tuples -- lane l takes pairs l, l + 64, ... : 12 bytes at dword 3 * pair, so the 64 lanes of a
 // read hit 64 different banks and the pair {2m, 2m + 1} needs no byte shuffling beyond one funnel shift.
 // f(i, pay0, h0, pay1, h1): tuples i (even) and i + 1 of the region.
+// A wave's FIRST chunk of a region, requested ahead of the walk (k_join_probe_direct6_pf: the next partition's loads leave while
+// the current one is probed).
+template <int CHUNK>
+struct PackedChunk {
+  static constexpr int NP = CHUNK * 6 / 16;
+  static constexpr int LPL = (NP + kWave - 1) / kWave;
+  uint4 v[LPL];
+  __device__ __forceinline__ void load(const char* region, uint32_t lo, uint32_t hi, unsigned wave, unsigned lane) {
+    const uint32_t c = lo / CHUNK + wave;
+#pragma unroll
+    for (int k = 0; k < LPL; ++k) {
+      const uint32_t piece = k * kWave + lane;
+      v[k] = make_uint4(0, 0, 0, 0);
+      if (c * CHUNK < hi && (NP % kWave == 0 || piece < (uint32_t)NP)) v[k] = gload4(region + ((uint64_t)c * NP + piece) * 16);
+    }
+  }
+};
+
 template <int CHUNK, class Fn>
 __device__ __forceinline__ void scan_packed(const char* region, uint32_t lo, uint32_t hi, char* stage, unsigned wave, unsigned nwaves,
-                                            unsigned lane, Fn&& f) {
+                                            unsigned lane, Fn&& f, const PackedChunk<CHUNK>* pre = nullptr) {
   static_assert(CHUNK % 128 == 0, "whole pairs per lane");
   constexpr int NP = CHUNK * 6 / 16;       // 16-byte vectors per chunk
   constexpr int LPL = (NP + kWave - 1) / kWave;
@@ -458,7 +476,12 @@ __device__ __forceinline__ void scan_packed(const char* region, uint32_t lo, uin
       if (NP % kWave == 0 || piece < (uint32_t)NP) v[k] = gload4(region + ((uint64_t)cc * NP + piece) * 16);
     }
   };
-  if (c < c1) load(c, cur);
+  if (pre) {
+#pragma unroll
+    for (int k = 0; k < LPL; ++k) cur[k] = pre->v[k];
+  } else if (c < c1) {
+    load(c, cur);
+  }
   for (; c < c1; c += nwaves) {
     if (c + nwaves < c1) load(c + nwaves, nxt);
 #pragma unroll
@@ -741,6 +764,145 @@ __global__ __launch_bounds__(BLOCK) void k_join_probe_direct6(PartView RV, PartV
   for (uint32_t p = blockIdx.x; p < nparts; p += gridDim.x) body(p, 0u);
   const uint32_t n_extra = slices.count ? min(*slices.count, slices.capacity) : 0u;
   for (uint32_t w = blockIdx.x; w < n_extra; w += gridDim.x) body(slices.list[w].x, slices.list[w].y);
+  const uint64_t wm = wave_reduce_add((uint64_t)my_miss);
+  const uint64_t wd = wave_reduce_add((uint64_t)my_dup);
+  const uint64_t wf = wave_reduce_add((uint64_t)my_foreign);
+  if (lane == 0) {
+    if (wm) atomicAdd(&counters[0], (unsigned long long)wm);
+    if (wd) atomicAdd(&counters[1], (unsigned long long)wd);
+    if (wf) atomicAdd(&counters[5], (unsigned long long)wf);
+  }
+  if (threadIdx.x == 0) atomicMax(&counters[3], (unsigned long long)my_max);
+}
+
+// k_join_probe_direct6<.., true, true> with the loads running AHEAD of the partition's phases: a small partition (2048 + 2048
+// tuples at 2^29 rows per side: one chunk per wave and side) is a chain of latencies -- sizes, build chunk, probe chunk -- so the
+// next work item's sizes are fetched while the table is built, its build chunk while the current one is probed, and the probe chunk
+// before the barrier that completes the table.  Work items: the partitions, then the (partition, slice >= 1) pairs.
+template <int BLOCK, int CHUNK>
+__global__ __launch_bounds__(BLOCK) void k_join_probe_direct6_pf(PartView RV, PartView LV, uint32_t nparts, uint32_t table_bits, uint32_t* out_fk,
+                                                                   uint32_t* out_y, uint32_t* out_x, uint32_t pair_store_ok,
+                                                                   unsigned long long* counters, uint32_t* miss_bits, ProbeSlices slices) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint32_t* s_vals = (uint32_t*)smem;
+  uint32_t* s_used = (uint32_t*)(smem + kDSlots * 4);
+  const unsigned lane = lane_id(), wave = threadIdx.x / kWave;
+  constexpr unsigned kNW = BLOCK / kWave;
+  char* stage = smem + kDSlots * 4 + kDSlots / 8 + wave * (CHUNK * 6);
+  const char* R = (const char*)RV.t;
+  const char* L = (const char*)LV.t;
+  const uint32_t slots = 1u << table_bits, smask = slots - 1;
+  uint32_t my_miss = 0, my_dup = 0, my_foreign = 0;
+  uint64_t my_max = 0;
+  const uint32_t n_extra = slices.count ? min(*slices.count, slices.capacity) : 0u;
+  const uint32_t total = nparts + n_extra;
+  struct Item {
+    uint32_t p, slice, n_r, n_l, top, rtop;
+    uint64_t dense;
+  };
+  auto fetch = [&](uint32_t w) -> Item {
+    Item it{0u, 0u, 0u, 0u, 0u, 0u, 0ull};
+    if (w < total) {
+      if (w < nparts) {
+        it.p = w;
+      } else {
+        const uint2 e = slices.list[w - nparts];
+        it.p = e.x;
+        it.slice = e.y;
+      }
+      it.n_r = RV.cnt[it.p];
+      it.n_l = LV.cnt[it.p];
+      it.top = LV.top[it.p];
+      it.rtop = RV.top[it.p];
+      it.dense = LV.dense[it.p];
+    }
+    return it;
+  };
+  auto range = [&](const Item& it, uint32_t& lb, uint32_t& le) {  // probe rows [lb, le) of the item's partition
+    lb = it.slice * kProbeSlice;
+    le = slices.count ? min(it.n_l, lb + kProbeSlice) : it.n_l;
+  };
+  PackedChunk<CHUNK> rpre, lpre;
+  Item cur = fetch(blockIdx.x);
+  {
+    uint32_t lb, le;
+    range(cur, lb, le);
+    if (lb < le) rpre.load(R + (uint64_t)cur.p * RV.cap * 6, 0u, cur.n_r, wave, lane);
+  }
+  for (uint32_t w = blockIdx.x; w < total; w += gridDim.x) {
+    const Item nxt = fetch(w + gridDim.x);  // (its figures arrive while this item's table is built)
+    uint32_t lb, le;
+    range(cur, lb, le);
+    if (cur.n_r > my_max) my_max = cur.n_r;
+    const bool work = lb < le;
+    if (work) {
+      lpre.load(L + (uint64_t)cur.p * LV.cap * 6, lb, le, wave, lane);  // (in flight while the table is built)
+      if (cur.n_r && cur.rtop != cur.top && threadIdx.x == 0) my_foreign += cur.n_l;
+      for (uint32_t i = threadIdx.x; i < (slots + 31) / 32; i += BLOCK) s_used[i] = 0;
+      __syncthreads();
+      const uint32_t n_r = cur.n_r, slice = cur.slice;
+      scan_packed<CHUNK>(R + (uint64_t)cur.p * RV.cap * 6, 0u, n_r, stage, wave, kNW, lane,
+                         [&](uint32_t i, uint32_t p0, uint32_t h0, uint32_t p1, uint32_t h1) {
+#pragma unroll
+                           for (int h = 0; h < 2; ++h) {
+                             if (i + h >= n_r) continue;
+                             const uint32_t slot = (h ? h1 : h0) & smask;
+                             const uint32_t bit = 1u << (slot & 31);
+                             if ((atomicOr(&s_used[slot >> 5], bit) & bit) && slice == 0) ++my_dup;  // equal key overwrites (hashtable.c:133)
+                             s_vals[slot] = h ? p1 : p0;
+                           }
+                         },
+                         &rpre);
+      __syncthreads();
+    }
+    {  // the next item's first build chunk
+      uint32_t nlb, nle;
+      range(nxt, nlb, nle);
+      if (nlb < nle) rpre.load(R + (uint64_t)nxt.p * RV.cap * 6, 0u, nxt.n_r, wave, lane);
+    }
+    if (work) {
+      const uint64_t dense = cur.dense;
+      const uint32_t pair_store = pair_store_ok && ((dense + (pair_store_ok >> 1)) & 1) == 0;
+      const uint32_t top_bits = cur.top << table_bits;
+      scan_packed<CHUNK>(L + (uint64_t)cur.p * LV.cap * 6, lb, le, stage, wave, kNW, lane,
+                         [&](uint32_t i, uint32_t p0, uint32_t h0, uint32_t p1, uint32_t h1) {
+                           uint32_t xs[2], fk[2];
+                           bool ok[2];
+#pragma unroll
+                           for (int h = 0; h < 2; ++h) {
+                             ok[h] = i + h < le;
+                             const uint32_t slot = (h ? h1 : h0) & smask;
+                             fk[h] = wang_hash_inv(top_bits | slot);
+                             const bool hit = (s_used[slot >> 5] >> (slot & 31)) & 1u;
+                             xs[h] = s_vals[slot];
+                             if (ok[h] && !hit) {
+                               ++my_miss;
+                               if (miss_bits) atomicOr(&miss_bits[(i + h + dense) >> 5], 1u << ((i + h + dense) & 31));  // drop mode: mark the row
+                             }
+                           }
+                           const uint64_t o = i + dense;
+                           if (ok[0] && ok[1] && pair_store) {
+                             *(uint2*)(out_fk + o) = make_uint2(fk[0], fk[1]);
+                             *(uint2*)(out_y + o) = make_uint2(p0, p1);
+                             *(uint2*)(out_x + o) = make_uint2(xs[0], xs[1]);
+                           } else {
+                             if (ok[0]) {
+                               out_fk[o] = fk[0];
+                               out_y[o] = p0;
+                               out_x[o] = xs[0];
+                             }
+                             if (ok[1]) {
+                               out_fk[o + 1] = fk[1];
+                               out_y[o + 1] = p1;
+                               out_x[o + 1] = xs[1];
+                             }
+                           }
+                         },
+                         &lpre);
+      __syncthreads();
+    }
+    cur = nxt;
+  }
   const uint64_t wm = wave_reduce_add((uint64_t)my_miss);
   const uint64_t wd = wave_reduce_add((uint64_t)my_dup);
   const uint64_t wf = wave_reduce_add((uint64_t)my_foreign);

@@ -329,6 +329,8 @@ int olap_join_configure(olap_ctx* ctx, int radix_bits_total, int max_bits_per_pa
  *                      0 always the exact-layout pipeline (histogram + scan + scatter per pass, 16-byte tuples) | 2 every plan of
  *                      8..18 radix bits (tests)
  *   join64_tpt         8 its passes of <= 256 buckets run 4096-tuple tiles (default) | 4 2048-tuple tiles, as passes of 512 buckets always do
+ *   probe6_prefetch    0 (default) | 1 the packed probe requests the next partition's sizes and first chunks ahead of the
+ *                      current partition's phases (k_join_probe_direct6_pf: SF=256 probe 3.0 -> 2.85 ms, SF=2048 18.1 -> 17.8 ms)
  *   direct_table       1 direct-address LDS table when <= 14 hash bits remain (default) | 0 probing table
  *   take_variant       0 automatic | 1 never the LDS-window kernel | 3 small gather tiles | 4 window-bucketed path
  *                      for batches whose data buffer is far larger than LDS (an alternative that measured slower)

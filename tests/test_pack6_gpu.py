@@ -36,7 +36,7 @@ def run_join(dev, fk, y, pk, x, rows, skip_bits, drop=False, knobs=None, radix_b
     """8 + 8 radix bits below `skip_bits` fixed ones -> 14 table bits: claiming pass 0, capacity-layout last pass, direct table.
     rows(n) -> batch lengths.  Returns (host columns, stats, (last-pass kernel, probe kernel), (attempts, overflows))."""
     o = _ops()
-    defaults = {"pack6": 1, "probe6_geometry": 0, "probe_slices": 1, "ring6_tpt": 8, "pack6_hash": 1, "claim_lean": 1, "contig_columns": 1}
+    defaults = {"pack6": 1, "probe6_geometry": 0, "probe6_prefetch": 0, "probe_slices": 1, "ring6_tpt": 8, "pack6_hash": 1, "claim_lean": 1, "contig_columns": 1}
     d, out = {}, {}
     try:
         d = {k: dev.to_device(v) for k, v in (("fk", fk), ("y", y), ("pk", pk), ("x", x))}
@@ -81,13 +81,14 @@ def ragged_batches(nb):
     return rows
 
 
-@pytest.mark.parametrize("geometry", [0, 1])
+@pytest.mark.parametrize("geometry", [0, 1, 2])
 @pytest.mark.parametrize("shape", ["uniform", "clustered_left", "clustered_both", "ragged", "misses"])
 def test_join_packed_tuples_rows_exact(dev, shape, geometry):
     """2^25 x 2^25 rows whose keys share their two leading hash bits (one owner's share of a 4-way split).  clustered_*: rows
     ordered by hash, so every tile of the last pass falls into a few buckets (ring overflow -> direct range writes in every
     tile); ragged: odd batch lengths; misses: foreign keys without a primary key, dropped (inner join) -- their rows must
-    disappear and nothing else.  Both probe geometries."""
+    disappear and nothing else.  Both probe geometries, and (geometry 2) the probe whose loads run ahead of the partition's
+    phases (probe6_prefetch)."""
     n = 1 << 25
     rng = np.random.default_rng(11)
     pk = owned_keys(n, owner=2)
@@ -110,8 +111,9 @@ def test_join_packed_tuples_rows_exact(dev, shape, geometry):
             pk, x = pk[order], x[order]
     y = np.arange(n, dtype=np.uint32)
     rows = even_batches(32) if shape != "ragged" else ragged_batches(33)
-    (ofk, oy, ox), stats, kernels, counters = run_join(dev, fk, y, pk, x, rows, 2, drop=(shape == "misses"), knobs={"probe6_geometry": geometry})
-    assert "k_part_scatter_ring6" in kernels[0] and "k_join_probe_direct6" in kernels[1] and kernels[1].endswith("true, true>"), kernels
+    (ofk, oy, ox), stats, kernels, counters = run_join(dev, fk, y, pk, x, rows, 2, drop=(shape == "misses"), knobs={"probe6_geometry": geometry} if geometry < 2 else {"probe6_prefetch": 1})
+    assert "k_part_scatter_ring6" in kernels[0] and "k_join_probe_direct6" in kernels[1], kernels
+    assert kernels[1].endswith("true, true>") if geometry < 2 else kernels[1] == "olap::k_join_probe_direct6_pf<512, 256>", kernels
     assert ("<1024, 512," in kernels[1]) == (geometry == 1), kernels
     assert counters == (1, 0), counters                                    # no exact rerun behind the result
     assert stats["radix_bits"][:2] == [8, 8] and stats["table_slots"] == 1 << 14, stats
