@@ -31,7 +31,7 @@ ArrowArray._fields_ = [
     ("dictionary", C.POINTER(ArrowArray)), ("release", C.CFUNCTYPE(None, C.POINTER(ArrowArray))), ("private_data", C.c_void_p),
 ]
 
-EXPORTS = ["olap_arrow_filter_lt", "olap_arrow_sum", "olap_arrow_take", "olap_arrow_join_u32"]
+EXPORTS = ["olap_arrow_filter_lt", "olap_arrow_sum", "olap_arrow_take", "olap_arrow_join_u32", "olap_arrow_join_u64"]
 _bound = False
 
 
@@ -45,6 +45,7 @@ def _lib():
         L.olap_arrow_sum.argtypes = [vp, C.POINTER(ArrowSchema), pp, u64, C.POINTER(u64)]
         L.olap_arrow_take.argtypes = [vp, C.POINTER(ArrowSchema), pp, pp, u64, C.POINTER(ArrowArray)]
         L.olap_arrow_join_u32.argtypes = [vp, pp, pp, u64, pp, pp, u64, C.POINTER(ArrowArray), C.POINTER(capi.JoinStats)]
+        L.olap_arrow_join_u64.argtypes = [vp, pp, pp, u64, pp, pp, u64, C.POINTER(ArrowArray), C.POINTER(capi.JoinStats)]
         for name in EXPORTS:
             getattr(L, name).restype = C.c_int
         _bound = True
@@ -146,20 +147,28 @@ def take(ctx: capi.Context, data, indices):
 
 
 def join(ctx: capi.Context, left_fk, left_y, right_pk, right_x):
-    """PK-FK join of chunked uint32 columns -> (pa.Table{fk, y, x}, stats).  left_y / right_x None:
-    y / x are the global row indices (selection vectors)."""
+    """PK-FK join of chunked columns -> (pa.Table{fk, y, x}, stats): uint32 keys (olap_arrow_join_u32) or uint64 / int64 keys
+    (olap_arrow_join_u64; fk keeps the key column's type), uint32 payloads.  left_y / right_x None: y / x are the global row
+    indices (selection vectors)."""
     import pyarrow as pa
     cols = [_chunks(c) if c is not None else None for c in (left_fk, left_y, right_pk, right_x)]
+    ktype = cols[0][0].type if cols[0] else pa.uint32()
+    wide = str(ktype) in ("uint64", "int64")
     ex = [_Exported(c) if c is not None else None for c in cols]
     outs = (ArrowArray * 3)()
     st = capi.JoinStats()
     tbl = lambda e: e.table if e is not None else None
+    fn = _lib().olap_arrow_join_u64 if wide else _lib().olap_arrow_join_u32
     try:
-        ctx._check(_lib().olap_arrow_join_u32(ctx.h, tbl(ex[0]), tbl(ex[1]), len(cols[0]), tbl(ex[2]), tbl(ex[3]), len(cols[2]),
-                                              outs, C.byref(st)))
+        ctx._check(fn(ctx.h, tbl(ex[0]), tbl(ex[1]), len(cols[0]), tbl(ex[2]), tbl(ex[3]), len(cols[2]), outs, C.byref(st)))
     finally:
         for e in ex:
             if e is not None:
                 e.release()
-    fk, y, x = _import(outs, 3, pa.uint32())
+    if wide:
+        fk = pa.Array._import_from_c(C.addressof(outs[0]), ktype)
+        y = pa.Array._import_from_c(C.addressof(outs[1]), pa.uint32())
+        x = pa.Array._import_from_c(C.addressof(outs[2]), pa.uint32())
+    else:
+        fk, y, x = _import(outs, 3, pa.uint32())
     return pa.table({"fk": fk, "y": y, "x": x}), st.as_dict()

@@ -212,4 +212,45 @@ int olap_arrow_join_u32(olap_ctx* ctx, const struct ArrowArray* const* left_fk, 
   return OLAP_OK;
 }
 
+// 64-bit keys (olap_join_u64): fk / pk as uint64 / int64 arrays, payloads uint32 / int32 (or NULL: selection vectors).
+// out_columns[0] = fk as 64-bit values, [1] = y, [2] = x (32-bit), all of left-row length (the rows of out_columns[0] first in
+// the block: 8-byte aligned).
+int olap_arrow_join_u64(olap_ctx* ctx, const struct ArrowArray* const* left_fk, const struct ArrowArray* const* left_y,
+                        uint64_t n_left_batches, const struct ArrowArray* const* right_pk, const struct ArrowArray* const* right_x,
+                        uint64_t n_right_batches, struct ArrowArray* out_columns, olap_join_stats* stats) {
+  if (!ctx) return OLAP_ERR_INVALID;
+  if (!out_columns) return ctx->fail(OLAP_ERR_INVALID, "null output array list");
+  std::vector<const void*> lk, ly, rk, rx;
+  std::vector<uint64_t> lrows, lyrows, rrows, rxrows;
+  OLAP_TRY(import_column(ctx, left_fk, n_left_batches, 8, &lk, &lrows));
+  OLAP_TRY(import_column(ctx, right_pk, n_right_batches, 8, &rk, &rrows));
+  if (left_y) {
+    OLAP_TRY(import_column(ctx, left_y, n_left_batches, 4, &ly, &lyrows));
+    if (lyrows != lrows) return ctx->fail(OLAP_ERR_INVALID, "left key and payload batches differ in length");
+  }
+  if (right_x) {
+    OLAP_TRY(import_column(ctx, right_x, n_right_batches, 4, &rx, &rxrows));
+    if (rxrows != rrows) return ctx->fail(OLAP_ERR_INVALID, "right key and payload batches differ in length");
+  }
+  uint64_t n_left = 0;
+  for (uint64_t r : lrows) n_left += r;
+  Block* block = new_block(n_left * 16);
+  if (!block) return ctx->fail(OLAP_ERR_NOMEM, "host allocation of %llu bytes failed", (unsigned long long)(n_left * 16));
+  uint64_t* ok = static_cast<uint64_t*>(block->base);
+  uint32_t* o32 = reinterpret_cast<uint32_t*>(ok + n_left);
+  uint64_t out_rows = 0;
+  auto k64 = [](const std::vector<const void*>& v) { return reinterpret_cast<const uint64_t* const*>(v.data()); };
+  auto p32 = [](const std::vector<const void*>& v) { return reinterpret_cast<const uint32_t* const*>(v.data()); };
+  const int rc = olap_join_u64(ctx, k64(lk), left_y ? p32(ly) : nullptr, lrows.data(), n_left_batches, k64(rk), right_x ? p32(rx) : nullptr,
+                               rrows.data(), n_right_batches, OLAP_MEM_HOST, ok, o32, o32 + n_left, n_left, OLAP_MEM_HOST, &out_rows, stats);
+  if (rc != OLAP_OK) {
+    drop_if_unused(block);
+    return rc;
+  }
+  export_array(&out_columns[0], block, ok, (int64_t)out_rows);
+  export_array(&out_columns[1], block, o32, (int64_t)out_rows);
+  export_array(&out_columns[2], block, o32 + n_left, (int64_t)out_rows);
+  return OLAP_OK;
+}
+
 }  // extern "C"

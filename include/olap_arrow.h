@@ -80,6 +80,14 @@ int olap_arrow_join_u32(olap_ctx* ctx, const struct ArrowArray* const* left_fk, 
                         const struct ArrowArray* const* right_x, uint64_t n_right_batches,
                         struct ArrowArray* out_columns /* 3 */, olap_join_stats* stats /* may be NULL */);
 
+/* The same join on 64-BIT KEYS (olap_join_u64; the reference's HT_64BIT_KEYS table, dpu/shared/hashtable/hashtable.h:13-18):
+ * fk / pk uint64 or int64 arrays, payloads uint32 / int32 arrays or NULL (selection vectors).  out_columns[0] = fk (64-bit
+ * values: import it with the key column's type), out_columns[1..3) = y, x (32-bit). */
+int olap_arrow_join_u64(olap_ctx* ctx, const struct ArrowArray* const* left_fk, const struct ArrowArray* const* left_y,
+                        uint64_t n_left_batches, const struct ArrowArray* const* right_pk,
+                        const struct ArrowArray* const* right_x, uint64_t n_right_batches,
+                        struct ArrowArray* out_columns /* 3 */, olap_join_stats* stats /* may be NULL */);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1194,7 +1194,18 @@ def test_arrow_c_data_interface_front_end(dev, golden):
     sel, _ = ac.join(dev, cut(fk, lrows), None, cut(pk, rrows), None)
     np.testing.assert_array_equal(pk[sel["x"].to_numpy()], sel["fk"].to_numpy())
     np.testing.assert_array_equal(fk[sel["y"].to_numpy()], sel["fk"].to_numpy())
-    del tbl, sel, out, out64                              # release callbacks run here
+    # 64-bit keys (olap_arrow_join_u64): golden case d (int64 keys, negatives included); fk keeps its type
+    fk8, y8, pk8, x8 = (golden[f"join_d_{k}"] for k in ("fk", "y", "pk", "x"))
+    l8, r8 = golden["join_d_left_rows"], golden["join_d_right_rows"]
+    t8, st8 = ac.join(dev, cut(fk8, l8), cut(y8, l8), cut(pk8, r8), cut(x8, r8))
+    assert st8["missing_keys"] == 0 and t8.num_rows == fk8.size and str(t8["fk"].type) == str(fk8.dtype)
+    a8, b8, c8 = sort_rows(*(t8[k].to_numpy() for k in ("fk", "y", "x")))
+    np.testing.assert_array_equal(a8, golden["join_d_out_fk"])
+    np.testing.assert_array_equal(b8, golden["join_d_out_y"])
+    np.testing.assert_array_equal(c8, golden["join_d_out_x"])
+    s8, _ = ac.join(dev, cut(fk8, l8), None, cut(pk8, r8), None)
+    np.testing.assert_array_equal(pk8[s8["x"].to_numpy()], s8["fk"].to_numpy())
+    del tbl, sel, out, out64, t8, s8                      # release callbacks run here
     with pytest.raises(ac.capi.OlapError):               # nulls are refused, not silently read
         ac.sum_(dev, pa.chunked_array([pa.array([1, None, 3], type=pa.uint32())]))
     # null_count == -1 ("not computed", legal in the C Data Interface) with a validity bitmap: the bitmap decides
