@@ -240,7 +240,7 @@ int olap_group_join_u32(olap_group* g, const uint32_t* const* left_fk_ptrs, cons
     uint64_t n = 0;
   };
   std::vector<Share> L(G), Rt(G);
-  uint64_t NL = 0, NR = 0;
+  uint64_t NL = 0;
   for (uint64_t b = 0; b < n_left_batches; ++b) {
     Share& s = L[b % G];
     s.k.push_back(left_fk_ptrs[b]);
@@ -255,7 +255,6 @@ int olap_group_join_u32(olap_group* g, const uint32_t* const* left_fk_ptrs, cons
     if (r_pay) s.p.push_back(right_x_ptrs[b]);
     s.rows.push_back(right_rows[b]);
     s.n += right_rows[b];
-    NR += right_rows[b];
   }
   if (NL > out_capacity) return g->fail(OLAP_ERR_CAPACITY, "output capacity %llu < %llu left rows", (unsigned long long)out_capacity, (unsigned long long)NL);
   if (NL && (!out_fk || !out_y || !out_x)) return g->fail(OLAP_ERR_INVALID, "null output column");

@@ -893,11 +893,10 @@ static int run_take(olap_ctx* ctx, const void* const* data_ptrs, const uint64_t*
     if (out_mem == OLAP_MEM_HOST)
       for (uint64_t b = b0; b < b1; ++b) need += align_up(idx_rows[b] * eb, 256);
     // choose the kernel by batch shape
-    uint64_t max_data = 0, max_idx = 0, sum_data = 0, sum_idx = 0;
+    uint64_t max_data = 0, max_idx = 0, sum_idx = 0;
     for (uint64_t b = b0; b < b1; ++b) {
       if (data_rows[b] > max_data) max_data = data_rows[b];
       if (idx_rows[b] > max_idx) max_idx = idx_rows[b];
-      sum_data += data_rows[b];
       sum_idx += idx_rows[b];
     }
     const bool lds_path = ctx->take_variant != 1 && max_idx <= (uint64_t)kTBlock * kTIdxPerThread &&
