@@ -336,14 +336,17 @@ static int launch_ring_as(olap_ctx* ctx, unsigned blocks, const PassSrc& src, ui
 }
 
 // ring scatter into the EXACT layout of a histogram + scan (4096-tuple tiles: the histogram must have counted the same tiles)
-template <int SRC>
+// (FULL as for the claiming pass: 1 / 2 = column input of whole, 16-byte aligned tiles with / without a payload column)
+template <int SRC, int FULL = 0>
 static int launch_ring_exact_as(olap_ctx* ctx, unsigned blocks, const PassSrc& src, uint32_t shift, uint32_t fbits, const uint32_t* hist,
                                 const uint64_t* seg_out, uint2* out) {
   constexpr uint32_t kLds = RingCfg<kRingFmax, kRingLine, kRingBlock, kRingProd>::kBytes;
-  auto kernel = k_part_scatter_ring<SRC, false, kRingFmax, kRingLine, kRingBlock, kRingProd, 8, 0, true>;
+  auto kernel = k_part_scatter_ring<SRC, false, kRingFmax, kRingLine, kRingBlock, kRingProd, 8, FULL, true>;
   OLAP_TRY(allow_lds(ctx, reinterpret_cast<const void*>(kernel), kLds));
-  ctx->phase_kernel[PH_PART_SCATTER] = SRC == SRC_COLS ? "olap::k_part_scatter_ring<0, false, 512, 16, 1024, 8, 8, 0, true>"
-                                                       : "olap::k_part_scatter_ring<1, false, 512, 16, 1024, 8, 8, 0, true>";
+  ctx->phase_kernel[PH_PART_SCATTER] = SRC != SRC_COLS ? "olap::k_part_scatter_ring<1, false, 512, 16, 1024, 8, 8, 0, true>"
+                                       : FULL == 1     ? "olap::k_part_scatter_ring<0, false, 512, 16, 1024, 8, 8, 1, true>"
+                                       : FULL == 2     ? "olap::k_part_scatter_ring<0, false, 512, 16, 1024, 8, 8, 2, true>"
+                                                       : "olap::k_part_scatter_ring<0, false, 512, 16, 1024, 8, 8, 0, true>";
   CapOut co{};
   co.hist = hist;
   co.seg_off = seg_out;
@@ -719,7 +722,10 @@ static int partition_side(olap_ctx* ctx, const ColumnSet& cs, bool has_payload, 
     {
       PhaseScope ps(ctx, PH_PART_SCATTER);
       if (ring_exact) {
-        if (cols) OLAP_TRY(launch_ring_exact_as<SRC_COLS>(ctx, (unsigned)blocks, src, shift, fbits, hist, seg_out, out));
+        const bool whole = cols && cs.full_units && cs.view.unit_rows == ring_tile(ctx) && ctx->ring_full_tiles && ctx->ring_tpt != 4;
+        if (cols && whole && has_payload) OLAP_TRY((launch_ring_exact_as<SRC_COLS, 1>(ctx, (unsigned)blocks, src, shift, fbits, hist, seg_out, out)));
+        else if (cols && whole) OLAP_TRY((launch_ring_exact_as<SRC_COLS, 2>(ctx, (unsigned)blocks, src, shift, fbits, hist, seg_out, out)));
+        else if (cols) OLAP_TRY(launch_ring_exact_as<SRC_COLS>(ctx, (unsigned)blocks, src, shift, fbits, hist, seg_out, out));
         else OLAP_TRY(launch_ring_exact_as<SRC_TUPLES>(ctx, (unsigned)blocks, src, shift, fbits, hist, seg_out, out));
       } else if (wc) {
         OLAP_TRY((launch_scatter<false>(ctx, cols, g2, fbits <= 9 && ctx->line16, (unsigned)blocks, src, shift, fbits, hist, seg_out,

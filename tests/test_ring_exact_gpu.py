@@ -110,3 +110,40 @@ def test_join_ring_exact_passes_random_plans(dev, seed):
     np.testing.assert_array_equal(fk[out["y"]], out["fk"])
     order = np.argsort(pk, kind="stable")
     np.testing.assert_array_equal(x[order][np.searchsorted(pk[order], out["fk"])], out["x"])
+
+
+@pytest.mark.parametrize("payload", [True, False])
+def test_partition_ring_exact_whole_tiles_straight_line_loader(dev, payload):
+    """Device-resident batches that are whole 4096-row tiles in 16-byte aligned buffers take the straight-line loader (FULL = 1 with
+    a payload column, 2 without: the payload is then the global row index); same contract."""
+    import torch
+    from dpu_olap_amd.dist_join import GpuLocalOps
+    device = torch.device("cuda", 0)
+    ops = GpuLocalOps(dev, device)
+    rng = np.random.default_rng(77)
+    sizes = [65536, 4096 * 3, 8192, 4096 * 50]
+    kk = [rng.integers(0, 1 << 32, size=n, dtype=np.uint32) for n in sizes]
+    pp = [rng.integers(0, 1 << 32, size=n, dtype=np.uint32) for n in sizes]
+    t = lambda a: torch.from_numpy(a.view(np.int32)).to(device)
+    P = 256
+    keys = [t(a) for a in kk]
+    if payload:
+        tup, off = ops.partition_tuples(keys, [t(a) for a in pp], P)
+        want = "1, true>"
+    else:
+        rows = [int(k.numel()) for k in keys]
+        n = sum(rows)
+        ok, op = ops.empty(n), ops.empty(n)
+        torch.cuda.current_stream(device).synchronize()
+        off = dev.partition_u32([k.data_ptr() for k in keys], None, rows, 1, P, ok.data_ptr(), op.data_ptr(), n, 1)   # MEM_DEVICE = 1
+        tup = (ok.cpu().numpy().view(np.uint32).astype(np.uint64) | (op.cpu().numpy().view(np.uint32).astype(np.uint64) << np.uint64(32)))
+        want = "2, true>"
+    assert dev.phase_kernel("partition-scatter").endswith(want), dev.phase_kernel("partition-scatter")
+    tup = tup.cpu().numpy().view(np.uint64) if payload else tup
+    allk = np.concatenate(kk)
+    allp = np.concatenate(pp) if payload else np.arange(allk.size, dtype=np.uint32)
+    exp = allk.astype(np.uint64) | (allp.astype(np.uint64) << np.uint64(32))
+    bucket = oracle.wang_hash_np(allk) >> np.uint32(32 - 8)
+    assert off[-1] == allk.size
+    for p in range(P):
+        np.testing.assert_array_equal(np.sort(tup[off[p]:off[p + 1]]), np.sort(exp[bucket == p]))
