@@ -336,8 +336,13 @@ int olap_group_join_u32(olap_group* g, const uint32_t* const* left_fk_ptrs, cons
       for (const Move& m : mv) {
         const char* sp = (const char*)(side ? g->tr[m.src].p : g->tl[m.src].p) + m.src_off * 8;
         char* dp = (char*)(side ? g->rr[m.dst].p : g->rl[m.dst].p) + m.dst_off * 8;
-        if (e == ncclSuccess) e = R.Send(sp, m.n, ncclUint64, m.dst, R.comms[m.src], (hipStream_t)olap_get_stream(g->ctx[m.src]));
-        if (e == ncclSuccess) e = R.Recv(dp, m.n, ncclUint64, m.src, R.comms[m.dst], (hipStream_t)olap_get_stream(g->ctx[m.dst]));
+        // (pieces of at most 512 MiB: this RCCL delivers a message of more than 1 GiB only in part, silently -- scripts/dbg_a2a.py)
+        constexpr uint64_t kPiece = 1ull << 26;
+        for (uint64_t at = 0; at < m.n && e == ncclSuccess; at += kPiece) {
+          const uint64_t cnt = std::min(kPiece, m.n - at);
+          e = R.Send(sp + at * 8, cnt, ncclUint64, m.dst, R.comms[m.src], (hipStream_t)olap_get_stream(g->ctx[m.src]));
+          if (e == ncclSuccess) e = R.Recv(dp + at * 8, cnt, ncclUint64, m.src, R.comms[m.dst], (hipStream_t)olap_get_stream(g->ctx[m.dst]));
+        }
       }
     }
     const ncclResult_t e2 = R.GroupEnd();

@@ -23,6 +23,7 @@ gloo in tests (tests provide an oracle-backed ops object); the product backend i
 GpuLocalOps (C ABI on device pointers of torch CUDA tensors)."""
 from __future__ import annotations
 
+import os
 import time
 from typing import Sequence
 
@@ -234,11 +235,49 @@ def _pairwise_only(group) -> bool:
     return dist.get_backend(group) == "gloo"
 
 
-def _exchange(send: torch.Tensor, in_splits, out_splits, empty, group, async_op: bool = False):
+# RCCL (torch 2.10 + ROCm 7) moves a message of more than 1 GiB only in part, SILENTLY (scripts/dbg_a2a.py: a 2 GiB
+# all_to_all_single at world size 1 delivers its first GiB).  Messages above this many elements therefore travel in rounds of
+# list-form all_to_alls over views of the same buffers; every rank must run the same number of rounds, so the largest
+# message of the whole exchange travels with the counts (_split).
+MAX_MESSAGE_ELEMS = int(os.environ.get("OLAP_MAX_MESSAGE_ELEMS", 1 << 26))      # int64 tuples: 512 MiB (the override is for tests)
+
+
+class _PendingMany:
+    """Several collectives in flight that fill one receive buffer."""
+
+    def __init__(self, recv, works):
+        self.recv, self.works = recv, works
+
+    def wait(self):
+        for w in self.works:
+            if w is not None:
+                w.wait()
+        return self.recv
+
+
+def _exchange(send: torch.Tensor, in_splits, out_splits, empty, group, async_op: bool = False, largest: int | None = None):
     """Personalised all-to-all of a 1-D tensor.  RCCL/NCCL: all_to_all_single (optionally
     asynchronous, so it overlaps the partition kernels of the other table); gloo builds
-    without it: pairwise isend/irecv."""
+    without it: pairwise isend/irecv.  largest: the largest per-peer message of this exchange over ALL ranks (None: unknown --
+    then only a one-rank group, which knows it, splits oversized messages)."""
     recv = empty(int(sum(out_splits)))
+    world = dist.get_world_size(group)
+    if largest is None and world == 1:
+        largest = max([int(v) for v in in_splits] + [0])
+    if largest is not None and largest > MAX_MESSAGE_ELEMS and not _pairwise_only(group):
+        so, ro = [0], [0]
+        for v in in_splits:
+            so.append(so[-1] + int(v))
+        for v in out_splits:
+            ro.append(ro[-1] + int(v))
+        works = []
+        for r in range((largest + MAX_MESSAGE_ELEMS - 1) // MAX_MESSAGE_ELEMS):
+            lo = r * MAX_MESSAGE_ELEMS
+            piece = lambda base, n: (base + min(lo, n), base + min(lo + MAX_MESSAGE_ELEMS, n))
+            ins = [send[slice(*piece(so[p], int(in_splits[p])))] for p in range(world)]
+            outs = [recv[slice(*piece(ro[p], int(out_splits[p])))] for p in range(world)]
+            works.append(dist.all_to_all(outs, ins, group=group, async_op=async_op))
+        return _PendingMany(recv, works) if async_op else recv
     try:
         work = dist.all_to_all_single(recv, send, output_split_sizes=list(out_splits), input_split_sizes=list(in_splits),
                                       group=group, async_op=async_op)
@@ -302,14 +341,15 @@ class _Shipped:
     pend[g].wait() -> what this rank received for group g (sender-major, then low sub-bucket);
     recv[q][g][l] = tuples sender q shipped for (group g, low sub-bucket l); sent[g][p], got[g][q] = message sizes."""
 
-    def __init__(self, ops, t, off, recv, sent, got, world, L, group):
+    def __init__(self, ops, t, off, recv, sent, got, world, L, group, largest=None):
         self.ops, self.t, self.off, self.recv, self.sent, self.got = ops, t, off, recv, sent, got
         self.world, self.L, self.group = world, L, group
+        self.largest = largest      # the largest message (tuples) any rank sends any peer for any group of this slice
         self.pend = [None] * len(sent)
 
     def ship(self, g: int):
         run = self.t[self.off[g * self.world * self.L]:self.off[(g + 1) * self.world * self.L]]   # everything group g sends, owner-major
-        self.pend[g] = _exchange(run, self.sent[g], self.got[g], self.ops.empty_tuples, self.group, async_op=True)
+        self.pend[g] = _exchange(run, self.sent[g], self.got[g], self.ops.empty_tuples, self.group, async_op=True, largest=self.largest)
 
     def ship_all(self):
         for g in range(len(self.pend)):
@@ -323,11 +363,15 @@ def _split(ops, keys, payload, world: int, gbits: int, lbits: int, group) -> _Sh
     obits, K, L = world.bit_length() - 1, 1 << gbits, 1 << lbits
     t, off = ops.split_tuples(keys, payload, obits, gbits, lbits)          # bucket order (group, owner, low)
     cnt = torch.tensor([off[k + 1] - off[k] for k in range(K * world * L)], dtype=torch.int64).view(K, world, L)
-    to_peers = cnt.permute(1, 0, 2).contiguous().view(-1)                 # per owner: its K x L counts
-    recv = _exchange_counts(to_peers.to(t.device), world, group).view(world, K, L).cpu()
     sent = [[int(v) for v in cnt[g].sum(1)] for g in range(K)]
+    # per owner: its K x L counts, and this rank's largest message (so that every rank learns the largest of all: _exchange)
+    mine = max(max(row) for row in sent) if sent else 0
+    to_peers = torch.cat([cnt.permute(1, 0, 2).contiguous().view(world, K * L), torch.full((world, 1), mine, dtype=torch.int64)], dim=1).view(-1)
+    back = _exchange_counts(to_peers.to(t.device), world, group).view(world, K * L + 1).cpu()
+    recv = back[:, :K * L].contiguous().view(world, K, L)
+    largest = int(back[:, K * L].max())
     got = [[int(v) for v in recv[:, g].sum(1)] for g in range(K)]
-    return _Shipped(ops, t, off, recv, sent, got, world, L, group)
+    return _Shipped(ops, t, off, recv, sent, got, world, L, group, largest)
 
 
 def _group_tables(slices, g: int, world: int, L: int, width: int):
