@@ -111,6 +111,8 @@ struct olap_ctx {
   int presplit_sub = 1;    // pre-split joins with one pass left: that pass chunk by chunk into packed sub-partitions (0 never, 1 when the chunks fill the chip, 2 always)
   int join64_ring = 1;     // olap_join_u64: the histogram-free plan on 12-byte tuples (ring64.h): 0 never, 1 automatic, 2 every two-pass plan of 4..9 bits per pass
   int join64_tpt = 8;      // ... tuples per producer thread and tile of its passes of <= 256 buckets (8 | 4; 512 buckets always take 4)
+  int probe64_variant = 5; // k64_probe12 (ring64.h): W + 4 * DH -- W tuples of a thread probe together (1 | 2), DH double hashing instead of linear probing
+  int probe64_grid = 24;   // ... workgroups per CU of its grid (three are resident; 8: +5 %, profiles/r3_probe64_ab.md)
   int ring6_tpt = 8;       // packed last pass: tuples per producer thread and tile (8: 4096-tuple tiles flushed at once; 4: 2048-tuple tiles, the flush one tile behind the insert)
   int probe6_prefetch = 0; // packed probe: the next partition's sizes and first chunks are requested ahead (k_join_probe_direct6_pf)
   int probe6_geometry = 0; // packed probe: 0 two workgroups of 512 per CU, 1 one workgroup of 1024

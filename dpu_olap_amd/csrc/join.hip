@@ -1317,6 +1317,16 @@ int olap_set_tuning(olap_ctx* ctx, const char* key, int value) {
     ctx->join64_tpt = value;
     return OLAP_OK;
   }
+  if (!std::strcmp(key, "probe64_variant")) {
+    if (value != 1 && value != 2 && value != 5 && value != 6) return ctx->fail(OLAP_ERR_INVALID, "probe64_variant must be W + 4 * DH with W in 1..2");
+    ctx->probe64_variant = value;
+    return OLAP_OK;
+  }
+  if (!std::strcmp(key, "probe64_grid")) {
+    if (value < 1 || value > 64) return ctx->fail(OLAP_ERR_INVALID, "probe64_grid must be in [1, 64]");
+    ctx->probe64_grid = value;
+    return OLAP_OK;
+  }
   if (!std::strcmp(key, "ring6_tpt")) {
     if (value != 4 && value != 8) return ctx->fail(OLAP_ERR_INVALID, "ring6_tpt must be 4 or 8");
     ctx->ring6_tpt = value;

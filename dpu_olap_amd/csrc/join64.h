@@ -292,7 +292,7 @@ static int join64_once(olap_ctx* ctx, const uint64_t* const* lfk, const uint32_t
   {
     PhaseScope ps(ctx, PH_JOIN_PROBE);
     ctx->phase_kernel[PH_JOIN_PROBE] = ring ? "olap::k64_probe12" : "olap::k64_probe";
-    const uint64_t grid = std::min<uint64_t>((uint64_t)ctx->compute_units * 8, P);
+    const uint64_t grid = std::min<uint64_t>((uint64_t)ctx->compute_units * (ring ? ctx->probe64_grid : 8), P);
     ProbeSlices slices{nullptr, nullptr, 0};  // probe partitions longer than one slice (a hot foreign key) become several work items
     if (ctx->probe_slices) {
       slices.capacity = (uint32_t)std::min<uint64_t>(NL / kProbeSlice + 1, 0xFFFFFFFFull);
@@ -303,10 +303,17 @@ static int join64_once(olap_ctx* ctx, const uint64_t* const* lfk, const uint32_t
       const PartView lv{nullptr, loff, ls.cnt, ls.dense, ls.cap, nullptr};
       hipLaunchKernelGGL(k_probe_slices, dim3((P + 255) / 256), dim3(256), 0, ctx->stream, lv, P, slices);
     }
-    if (ring)
-      hipLaunchKernelGGL(k64_probe12, dim3((unsigned)grid), dim3(k64Block), 0, ctx->stream, Part12{rs.t, rs.cnt, rs.dense, rs.cap},
+    if (ring) {
+      auto kern = k64_probe12<1, false>;
+      switch (ctx->probe64_variant) {  // W + 4 * DH
+        case 2: kern = k64_probe12<2, false>; break;
+        case 5: kern = k64_probe12<1, true>; break;
+        case 6: kern = k64_probe12<2, true>; break;
+        default: break;
+      }
+      hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(k64Block), 0, ctx->stream, Part12{rs.t, rs.cnt, rs.dense, rs.cap},
                          Part12{ls.t, ls.cnt, ls.dense, ls.cap}, P, d_fk, d_y, d_x, d_cnt, miss_bits, slices);
-    else
+    } else
       hipLaunchKernelGGL(k64_probe, dim3((unsigned)grid), dim3(k64Block), 0, ctx->stream, (const uint4*)Rt, roff, (const uint4*)Lt, loff, P, d_fk,
                          d_y, d_x, d_cnt, miss_bits, slices);
     OLAP_HIP(ctx, hipGetLastError());

@@ -597,8 +597,13 @@ __global__ __launch_bounds__(BLOCK) void k64_ring(PassSrc s, uint32_t shift, uin
 
 // ------------------------------------------------------------------ build + probe over the capacity layout
 // k64_probe (radix64.h) over partitions of 12-byte tuples: partition p = tuples [p * cap, p * cap + cnt[p]) of its side,
-// result rows at dense[p] + i (left side).  Same table: 4096 slots, 64-bit keys, linear probing, slot = ht_hash64(key) &
+// result rows at dense[p] + i (left side).  Same table: 4096 slots, 64-bit keys, open addressing from slot = ht_hash64(key) &
 // (slots - 1) (hashtable.c:99-101), an equal key overwrites (hashtable.c:133).
+//   W   tuples of a thread whose probing sequences advance TOGETHER: one LDS round trip per step for all of them instead of one
+//       divergent loop per tuple after the other (1 | 2; three and more spill at six waves per SIMD -- profiles/r3_probe64_ab.md)
+//   DH  double hashing: a key steps through the table by an odd number taken from its hash bits above the slot bits, so keys
+//       that meet part again.  The slowest lane of a wave sets the pace of its loop, and linear probing's clusters make that
+//       lane's sequence long.  (The table is internal: the rows do not depend on where a key sits.)
 struct Part12 {
   const Tuple12* t;
   const uint32_t* cnt;
@@ -606,6 +611,7 @@ struct Part12 {
   uint32_t cap;
 };
 
+template <int W, bool DH>
 __global__ __launch_bounds__(k64Block) __attribute__((amdgpu_waves_per_eu(6, 6))) void k64_probe12(Part12 RV, Part12 LV, uint32_t nparts, uint64_t* out_fk, uint32_t* out_y, uint32_t* out_x,
                                                          unsigned long long* counters, uint32_t* miss_bits, ProbeSlices slices) {
   __shared__ unsigned long long s_keys[k64Slots];
@@ -619,6 +625,7 @@ __global__ __launch_bounds__(k64Block) __attribute__((amdgpu_waves_per_eu(6, 6))
   constexpr int kU = 6;                              // tuples per thread and chunk: one chunk holds any build side the table admits
   constexpr uint32_t kChunk = kU * k64Block;
   static_assert(kChunk >= k64TableCap, "a build side is one chunk");
+  static_assert(kU % W == 0, "whole groups");
   const uint32_t n_extra = slices.count ? min(*slices.count, slices.capacity) : 0u;
   const uint32_t total = nparts + n_extra;           // work items: the partitions, then the (partition, slice >= 1) pairs
   struct Item {
@@ -655,6 +662,13 @@ __global__ __launch_bounds__(k64Block) __attribute__((amdgpu_waves_per_eu(6, 6))
       if (i < hi) v[u] = gload_tuple12(base + i);
     }
   };
+  auto key_of = [](const Tuple12& t) { return ((unsigned long long)t.hi << 32) | t.lo; };
+  // where a key's sequence starts and how far it steps
+  auto seq_of = [](unsigned long long k, uint32_t& slot, uint32_t& step) {
+    const uint32_t h = ht_hash64(k);
+    slot = h & (k64Slots - 1);  // hashtable.c:99-101
+    step = DH ? ((h >> 12) | 1u) & (k64Slots - 1) : 1u;
+  };
   Tuple12 Rv[kU], Lv[kU];
   Item cur = fetch(blockIdx.x);
   {
@@ -675,23 +689,37 @@ __global__ __launch_bounds__(k64Block) __attribute__((amdgpu_waves_per_eu(6, 6))
       if (threadIdx.x == 0) s_sp[0] = 0;
       __syncthreads();
 #pragma unroll
-      for (int u = 0; u < kU; ++u) {  // build: table[pk] = x
-        if (u * k64Block + threadIdx.x >= cur.n_r) continue;
-        const unsigned long long k = ((unsigned long long)Rv[u].hi << 32) | Rv[u].lo;
-        if (k == k64Empty) {
-          s_sp[1] = Rv[u].pay;
-          if (atomicExch(&s_sp[0], 1u) && cur.slice == 0) ++my_dup;
-          continue;
-        }
-        uint32_t slot = ht_hash64(k) & (k64Slots - 1);  // hashtable.c:99-101
-        for (uint32_t step = 0; step < k64Slots; ++step) {
-          const unsigned long long old = atomicCAS(&s_keys[slot], k64Empty, k);
-          if (old == k64Empty || old == k) {  // free cell, or an equal key overwrites (hashtable.c:133)
-            s_vals[slot] = Rv[u].pay;
-            if (old == k && cur.slice == 0) ++my_dup;
-            break;
+      for (int g = 0; g < kU; g += W) {  // build: table[pk] = x
+        uint32_t slot[W], step[W], act = 0;
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+          const unsigned long long k = key_of(Rv[g + j]);
+          seq_of(k, slot[j], step[j]);
+          if ((g + j) * k64Block + threadIdx.x >= cur.n_r) continue;
+          if (k == k64Empty) {
+            s_sp[1] = Rv[g + j].pay;
+            if (atomicExch(&s_sp[0], 1u) && cur.slice == 0) ++my_dup;
+          } else {
+            act |= 1u << j;
           }
-          slot = (slot + 1) & (k64Slots - 1);
+        }
+        while (act) {  // (ends: a table admits at most 3/4 of its slots)
+          unsigned long long old[W];
+#pragma unroll
+          for (int j = 0; j < W; ++j)
+            if (act >> j & 1u) old[j] = atomicCAS(&s_keys[slot[j]], k64Empty, key_of(Rv[g + j]));
+#pragma unroll
+          for (int j = 0; j < W; ++j) {
+            if (!(act >> j & 1u)) continue;
+            const unsigned long long k = key_of(Rv[g + j]);
+            if (old[j] == k64Empty || old[j] == k) {  // free cell, or an equal key overwrites (hashtable.c:133)
+              s_vals[slot[j]] = Rv[g + j].pay;
+              if (old[j] == k && cur.slice == 0) ++my_dup;
+              act &= ~(1u << j);
+            } else {
+              slot[j] = (slot[j] + step[j]) & (k64Slots - 1);
+            }
+          }
         }
       }
       load_chunk(L, lb, le, Lv);
@@ -706,36 +734,59 @@ __global__ __launch_bounds__(k64Block) __attribute__((amdgpu_waves_per_eu(6, 6))
       for (uint32_t base = lb; base < le; base += kChunk) {  // probe + take of the right payload
         if (base != lb) load_chunk(L, base, le, Lv);
 #pragma unroll
-        for (int u = 0; u < kU; ++u) {
-          const uint32_t i = base + u * k64Block + threadIdx.x;
-          if (i >= le) continue;
-          const unsigned long long k = ((unsigned long long)Lv[u].hi << 32) | Lv[u].lo;
-          uint32_t xv = 0;
-          bool hit = false;
-          if (k == k64Empty) {
-            hit = s_sp[0] != 0;
-            xv = s_sp[1];
-          } else {
-            uint32_t slot = ht_hash64(k) & (k64Slots - 1);
-            for (uint32_t step = 0; step < k64Slots; ++step) {
-              const unsigned long long kk = s_keys[slot];
-              if (kk == k) {
-                xv = s_vals[slot];
-                hit = true;
-                break;
+        for (int g = 0; g < kU; g += W) {
+          uint32_t slot[W], step[W], xs[W], act = 0, hit = 0;
+#pragma unroll
+          for (int j = 0; j < W; ++j) {
+            const unsigned long long k = key_of(Lv[g + j]);
+            seq_of(k, slot[j], step[j]);
+            xs[j] = 0;
+            if (base + (g + j) * k64Block + threadIdx.x >= le) continue;
+            if (k == k64Empty) {
+              if (s_sp[0] != 0) {
+                hit |= 1u << j;
+                xs[j] = s_sp[1];
               }
-              if (kk == k64Empty) break;
-              slot = (slot + 1) & (k64Slots - 1);
+            } else {
+              act |= 1u << j;
             }
           }
-          const uint64_t o = cur.dense + i;
-          if (!hit) {
-            ++my_miss;
-            if (miss_bits) atomicOr(&miss_bits[o >> 5], 1u << (o & 31));
+          uint32_t found = 0;
+          while (act) {
+            unsigned long long kk[W];
+#pragma unroll
+            for (int j = 0; j < W; ++j)
+              if (act >> j & 1u) kk[j] = s_keys[slot[j]];
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+              if (!(act >> j & 1u)) continue;
+              if (kk[j] == key_of(Lv[g + j])) {
+                found |= 1u << j;
+                act &= ~(1u << j);
+              } else if (kk[j] == k64Empty) {
+                act &= ~(1u << j);
+              } else {
+                slot[j] = (slot[j] + step[j]) & (k64Slots - 1);
+              }
+            }
           }
-          out_fk[o] = k;
-          out_y[o] = Lv[u].pay;
-          out_x[o] = xv;
+#pragma unroll
+          for (int j = 0; j < W; ++j)
+            if (found >> j & 1u) xs[j] = s_vals[slot[j]];
+          hit |= found;
+#pragma unroll
+          for (int j = 0; j < W; ++j) {
+            const uint32_t i = base + (g + j) * k64Block + threadIdx.x;
+            if (i >= le) continue;
+            const uint64_t o = cur.dense + i;
+            if (!(hit >> j & 1u)) {
+              ++my_miss;
+              if (miss_bits) atomicOr(&miss_bits[o >> 5], 1u << (o & 31));
+            }
+            out_fk[o] = key_of(Lv[g + j]);
+            out_y[o] = Lv[g + j].pay;
+            out_x[o] = xs[j];
+          }
         }
       }
       __syncthreads();

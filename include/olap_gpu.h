@@ -329,6 +329,10 @@ int olap_join_configure(olap_ctx* ctx, int radix_bits_total, int max_bits_per_pa
  *                      0 always the exact-layout pipeline (histogram + scan + scatter per pass, 16-byte tuples) | 2 every plan of
  *                      8..18 radix bits (tests)
  *   join64_tpt         8 its passes of <= 256 buckets run 4096-tuple tiles (default) | 4 2048-tuple tiles, as passes of 512 buckets always do
+ *   probe64_variant    5 the probe of that plan (k64_probe12): W + 4 * DH -- W = 1 | 2 tuples of a thread step through the table
+ *                      together, DH = 1 double hashing (default) | 0 linear probing as in hashtable.c (the table is internal: rows
+ *                      do not depend on it)
+ *   probe64_grid       24 ... its workgroups per CU (1..64)
  *   probe6_prefetch    0 (default) | 1 the packed probe requests the next partition's sizes and first chunks ahead of the
  *                      current partition's phases (k_join_probe_direct6_pf: SF=256 probe 3.0 -> 2.85 ms, SF=2048 18.1 -> 17.8 ms)
  *   direct_table       1 direct-address LDS table when <= 14 hash bits remain (default) | 0 probing table

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--ring", type=int, default=1, help="join64_ring tuning: 0 exact-layout pipeline, 1 automatic, 2 forced")
     ap.add_argument("--tpt", type=int, default=8)
     ap.add_argument("--bits", type=int, default=-1)
+    ap.add_argument("--probe", default="", help="A/B of the probe: comma list of variant:grid pairs (probe64_variant, probe64_grid), e.g. 0:8,1:3")
     a = ap.parse_args()
     n, br = 1 << a.log2_rows, 1 << a.log2_batch
     nb = n // br
@@ -45,24 +46,34 @@ def main():
     tbl = lambda name: [cols[name][0] + b * br * cols[name][1] for b in range(nb)]
     run = lambda: ctx.join_u64(tbl("fk"), tbl("y"), [br] * nb, tbl("pk"), tbl("x"), [br] * nb, capi.MEM_DEVICE, out_fk, out_y, out_x,
                                n, capi.MEM_DEVICE)
-    run()
-    ctx.set_profiling(True)
-    ctx.reset_timers()
-    ctx.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        got, stats = run()
-    ctx.synchronize()
-    ms = (time.perf_counter() - t0) / a.steps * 1e3
-    hx = np.empty(n, dtype=np.uint32)
-    ctx.d2h(hx.ctypes.data, out_x, hx.nbytes)
-    ok = got == n and int(hx.astype(np.int64).sum()) == want_sum
-    tm = {k: round(v["ms"] / a.steps, 3) for k, v in ctx.timers().items()}
-    # compulsory bytes per row pair: 12 + 12 read, 16 written
-    print(json.dumps({"metric": "join_u64 rows/s (left rows per second)", "rows_per_side": n, "ms_per_join": round(ms, 3),
-                      "value_Grows_s": round(n / ms / 1e6, 2), "algorithmic_GBps": round(n * 40 / ms / 1e6, 1), "verified": bool(ok),
-                      "moved_bytes_per_pair": 136 if "probe12" in ctx.phase_kernel("join-probe") else 224,
-                      "attempts": ctx.get_counter("join_attempts"), "probe_kernel": ctx.phase_kernel("join-probe"), "stats": stats, "phase_ms": tm}))
+    for cfg in (a.probe.split(",") if a.probe else [""]):
+        if cfg:
+            var, grid = (int(v) for v in cfg.split(":"))
+            ctx.set_tuning("probe64_variant", var)
+            ctx.set_tuning("probe64_grid", grid)
+        try:
+            run()
+        except capi.OlapError as e:
+            if not cfg:
+                raise
+            print(json.dumps({"probe": cfg, "error": str(e)[:120]}))  # (the diagnostic variants produce wrong rows)
+        ctx.set_profiling(True)
+        ctx.reset_timers()
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            got, stats = run()
+        ctx.synchronize()
+        ms = (time.perf_counter() - t0) / a.steps * 1e3
+        hx = np.empty(n, dtype=np.uint32)
+        ctx.d2h(hx.ctypes.data, out_x, hx.nbytes)
+        ok = got == n and int(hx.astype(np.int64).sum()) == want_sum
+        tm = {k: round(v["ms"] / a.steps, 3) for k, v in ctx.timers().items()}
+        # compulsory bytes per row pair: 12 + 12 read, 16 written
+        print(json.dumps({"probe": cfg, "metric": "join_u64 rows/s (left rows per second)", "rows_per_side": n, "ms_per_join": round(ms, 3),
+                          "value_Grows_s": round(n / ms / 1e6, 2), "algorithmic_GBps": round(n * 40 / ms / 1e6, 1), "verified": bool(ok),
+                          "moved_bytes_per_pair": 136 if "probe12" in ctx.phase_kernel("join-probe") else 224,
+                          "attempts": ctx.get_counter("join_attempts"), "probe_kernel": ctx.phase_kernel("join-probe"), "stats": stats, "phase_ms": tm}))
 
 
 if __name__ == "__main__":
