@@ -9,6 +9,56 @@
 
 namespace olap {
 
+// ------------------------------------------------------------ the probing table's sequences
+// Open addressing in an LDS table of SLOTS cells.  A key's sequence starts at the reference's cell (low hash bits,
+// hashtable.c:99-101) and steps by an ODD number of its own (double hashing; the reference probes linearly, hashtable.c:120-141):
+// the slowest lane of a wave sets the pace of its loop, and linear probing's clusters make that lane's sequence long.  The table
+// is internal -- which cell a key sits in never shows in the rows.  The loops run under an active flag, without a step bound
+// (a table admits at most 3/4 of its cells) and without a break: the bounded `for (...) { ...; break; }` form of rounds 1-2
+// compiled to far slower code (profiles/r3_probe64_ab.md).
+template <uint32_t SLOTS>
+__device__ __forceinline__ void seq_of_hash(uint32_t h, uint32_t& slot, uint32_t& step) {
+  slot = h & (SLOTS - 1);
+  step = ((h * 0x9E3779B1u) >> (32 - __builtin_ctz(SLOTS))) | 1u;  // (partition-mates share the hash's TOP bits: mix the low ones up)
+}
+// table[k] = val for a valid tuple; true: the key was there already (it is overwritten, hashtable.c:133)
+template <uint32_t SLOTS, typename K>
+__device__ __forceinline__ bool table_put(K* keys, uint32_t* vals, K empty, K k, uint32_t h, uint32_t val, bool valid) {
+  uint32_t slot, step;
+  seq_of_hash<SLOTS>(h, slot, step);
+  bool act = valid, dup = false;
+  while (act) {
+    const K old = atomicCAS(&keys[slot], empty, k);
+    if (old == empty || old == k) {
+      vals[slot] = val;
+      dup = old == k;
+      act = false;
+    } else {
+      slot = (slot + step) & (SLOTS - 1);
+    }
+  }
+  return dup;
+}
+template <uint32_t SLOTS, typename K>
+__device__ __forceinline__ bool table_get(const K* keys, const uint32_t* vals, K empty, K k, uint32_t h, bool valid, uint32_t& x) {
+  uint32_t slot, step;
+  seq_of_hash<SLOTS>(h, slot, step);
+  bool act = valid, found = false;
+  while (act) {
+    const K kk = keys[slot];
+    if (kk == k) {
+      found = true;
+      act = false;
+    } else if (kk == empty) {
+      act = false;
+    } else {
+      slot = (slot + step) & (SLOTS - 1);
+    }
+  }
+  if (found) x = vals[slot];
+  return found;
+}
+
 // ------------------------------------------------------------ build + probe
 // counters: [0] missing keys, [1] duplicate build keys, [2] overflowing
 // partitions, [3] max build rows, [4] region overflows (radix passes), [5] tuples whose
@@ -111,17 +161,8 @@ __global__ __launch_bounds__(kJBlock, 4) void k_join_probe(PartView RV, PartView
             if (k == kEmpty) {
               s_sp[1] = val;
               if (atomicExch(&s_sp[0], 1u) && slice == 0) ++my_dup;
-            } else {
-              uint32_t slot = wang_hash(k) & (kSlots - 1);
-              for (uint32_t step = 0; step < kSlots; ++step) {
-                const uint32_t old = atomicCAS(&s_keys[slot], kEmpty, k);
-                if (old == kEmpty || old == k) {  // free cell, or equal key overwrites (hashtable.c:133)
-                  s_vals[slot] = val;
-                  if (old == k && slice == 0) ++my_dup;
-                  break;
-                }
-                slot = (slot + 1) & (kSlots - 1);
-              }
+            } else if (table_put<kSlots>(s_keys, s_vals, kEmpty, k, wang_hash(k), val, true) && slice == 0) {
+              ++my_dup;
             }
           }
         }
@@ -155,17 +196,7 @@ __global__ __launch_bounds__(kJBlock, 4) void k_join_probe(PartView RV, PartView
               hit = s_sp[0] != 0;
               xs[h] = s_sp[1];
             } else {
-              uint32_t slot = wang_hash(k) & (kSlots - 1);
-              for (uint32_t step = 0; step < kSlots; ++step) {
-                const uint32_t kk = s_keys[slot];
-                if (kk == k) {
-                  xs[h] = s_vals[slot];
-                  hit = true;
-                  break;
-                }
-                if (kk == kEmpty) break;
-                slot = (slot + 1) & (kSlots - 1);
-              }
+              hit = table_get<kSlots>(s_keys, s_vals, kEmpty, k, wang_hash(k), true, xs[h]);
             }
             if (!hit) {
               ++my_miss;
@@ -214,7 +245,7 @@ __global__ __launch_bounds__(kJBlock, 4) void k_join_probe(PartView RV, PartView
 // the chip stays busy, where 2^1 partitions of a one-bit plan would leave the whole probe side to two workgroups
 // (2^28 x 2^12 rows: 197 ms partitioned by one bit).  The reference always partitions
 // (host/join/join_dpu.cc:82-142); Arrow's hash join -- the Native path -- has this shape.  Table semantics as
-// k_join_probe (hashtable.c:89-192: slot = low hash bits, linear probing, an equal key overwrites).
+// k_join_probe (hashtable.c:89-192: first cell = low hash bits, an equal key overwrites; table_put / table_get above).
 constexpr int kBcTile = kJBlock * 8;  // rows per tile of the column views (8 per thread)
 
 __global__ __launch_bounds__(kJBlock, 4) void k_join_broadcast(PassSrc rs, PassSrc ls, uint32_t* out_fk, uint32_t* out_y,
@@ -243,16 +274,7 @@ __global__ __launch_bounds__(kJBlock, 4) void k_join_broadcast(PassSrc rs, PassS
           if (atomicExch(&s_sp[0], 1u)) ++my_dup;
           continue;
         }
-        uint32_t slot = wang_hash(k) & (kSlots - 1);
-        for (uint32_t step = 0; step < kSlots; ++step) {
-          const uint32_t old = atomicCAS(&s_keys[slot], kEmpty, k);
-          if (old == kEmpty || old == k) {  // free cell, or an equal key overwrites (hashtable.c:133)
-            s_vals[slot] = pay[i];
-            if (old == k) ++my_dup;
-            break;
-          }
-          slot = (slot + 1) & (kSlots - 1);
-        }
+        if (table_put<kSlots>(s_keys, s_vals, kEmpty, k, wang_hash(k), pay[i], true)) ++my_dup;
       }
     }
   }
@@ -274,17 +296,7 @@ __global__ __launch_bounds__(kJBlock, 4) void k_join_broadcast(PassSrc rs, PassS
           hit = s_sp[0] != 0;
           xs[i] = s_sp[1];
         } else {
-          uint32_t slot = wang_hash(k) & (kSlots - 1);
-          for (uint32_t step = 0; step < kSlots; ++step) {
-            const uint32_t kk = s_keys[slot];
-            if (kk == k) {
-              xs[i] = s_vals[slot];
-              hit = true;
-              break;
-            }
-            if (kk == kEmpty) break;
-            slot = (slot + 1) & (kSlots - 1);
-          }
+          hit = table_get<kSlots>(s_keys, s_vals, kEmpty, k, wang_hash(k), true, xs[i]);
         }
         if (!hit) {
           ++my_miss;

@@ -216,16 +216,7 @@ __global__ __launch_bounds__(k64Block) void k64_probe(const uint4* R, const uint
         if (atomicExch(&s_sp[0], 1u) && slice == 0) ++my_dup;
         continue;
       }
-      uint32_t slot = ht_hash64(k) & (k64Slots - 1);  // hashtable.c:99-101
-      for (uint32_t step = 0; step < k64Slots; ++step) {
-        const unsigned long long old = atomicCAS(&s_keys[slot], k64Empty, k);
-        if (old == k64Empty || old == k) {  // free cell, or an equal key overwrites (hashtable.c:133)
-          s_vals[slot] = v.z;
-          if (old == k && slice == 0) ++my_dup;
-          break;
-        }
-        slot = (slot + 1) & (k64Slots - 1);
-      }
+      if (table_put<k64Slots>(s_keys, s_vals, k64Empty, k, ht_hash64(k), v.z, true) && slice == 0) ++my_dup;  // first cell: hashtable.c:99-101
     }
     __syncthreads();
     for (uint64_t i = llo + threadIdx.x; i < lhi; i += k64Block) {  // probe + take of the right payload
@@ -237,17 +228,7 @@ __global__ __launch_bounds__(k64Block) void k64_probe(const uint4* R, const uint
         hit = s_sp[0] != 0;
         xv = s_sp[1];
       } else {
-        uint32_t slot = ht_hash64(k) & (k64Slots - 1);
-        for (uint32_t step = 0; step < k64Slots; ++step) {
-          const unsigned long long kk = s_keys[slot];
-          if (kk == k) {
-            xv = s_vals[slot];
-            hit = true;
-            break;
-          }
-          if (kk == k64Empty) break;
-          slot = (slot + 1) & (k64Slots - 1);
-        }
+        hit = table_get<k64Slots>(s_keys, s_vals, k64Empty, k, ht_hash64(k), true, xv);
       }
       if (!hit) {
         ++my_miss;
