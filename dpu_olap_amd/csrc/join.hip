@@ -1051,8 +1051,20 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
       hipLaunchKernelGGL(k_join_probe_direct, dim3((unsigned)dgrid), dim3(kDBlock), 0, ctx->stream, rv, lv, P, run, table_bits,
                          (uint32_t)ctx->hash_skip_bits, d_fk, d_y, d_x, pair_ok, d_cnt, miss_bits, slices);
     } else {
-      hipLaunchKernelGGL(k_join_probe, dim3((unsigned)grid), dim3(kJBlock), 0, ctx->stream, rv, lv, P, d_fk, d_y, d_x,
-                         pair_ok, d_cnt, miss_bits, slices);
+      // the small table when the build partitions are at the plan's target of <= 2048 rows on average (a partition above 3072
+      // rows sends the call back here with the large table: join_run)
+      const bool small = ctx->probe_small_table && !ctx->probe_big_once && NR / P <= 2048;
+      ctx->last_probe_slots = small ? 4096u : (uint32_t)kSlots;
+      if (small) {
+        ctx->phase_kernel[PH_JOIN_PROBE] = "olap::k_join_probe<4096>";
+        uint64_t sgrid = std::min<uint64_t>((uint64_t)ctx->compute_units * 16, P);
+        hipLaunchKernelGGL(k_join_probe<4096>, dim3((unsigned)sgrid), dim3(kJBlock), 0, ctx->stream, rv, lv, P, d_fk, d_y, d_x, pair_ok, d_cnt,
+                           miss_bits, slices);
+      } else {
+        ctx->phase_kernel[PH_JOIN_PROBE] = "olap::k_join_probe<8192>";
+        hipLaunchKernelGGL(k_join_probe<kSlots>, dim3((unsigned)grid), dim3(kJBlock), 0, ctx->stream, rv, lv, P, d_fk, d_y, d_x, pair_ok, d_cnt,
+                           miss_bits, slices);
+      }
     }
     OLAP_HIP(ctx, hipGetLastError());
   }
@@ -1103,7 +1115,7 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
     st->passes = plan.passes;
     for (int i = 0; i < 4; ++i) st->radix_bits[i] = i < plan.passes ? plan.bits[i] : 0;
     st->nr_partitions = P;
-    st->table_slots = direct ? (1u << table_bits) : (uint32_t)kSlots;
+    st->table_slots = direct ? (1u << table_bits) : bc ? (uint32_t)kSlots : ctx->last_probe_slots;
     st->left_rows = NL;
     st->right_rows = NR;
     st->max_build_rows = counters[3];
@@ -1163,7 +1175,9 @@ static int join_run(olap_ctx* ctx, const JoinIn& jin, uint64_t NL, uint64_t NR, 
   bool allow_capacity = true;
   ctx->last_join_attempts = 0;
   ctx->last_join_region_overflows = 0;
-  for (int attempt = 0; attempt < 4; ++attempt) {
+  ctx->probe_big_once = false;
+  ctx->last_probe_slots = 0;
+  for (int attempt = 0; attempt < 5; ++attempt) {
     ++ctx->last_join_attempts;
     OLAP_TRY(join_once(ctx, jb, out_fk, out_y, out_x, out_mem, NL, NR, bits, allow_capacity, stats, counters, &kept_rows,
                        attempt == 0 ? right_ready : nullptr));
@@ -1173,6 +1187,10 @@ static int join_run(olap_ctx* ctx, const JoinIn& jin, uint64_t NL, uint64_t NR, 
       continue;
     }
     if (counters[2] == 0) break;
+    if (ctx->last_probe_slots == 4096u && !jb.broadcast) {  // ... the small table: the same plan with the large one first
+      ctx->probe_big_once = true;
+      continue;
+    }
     bits += 2;  // a build partition overflowed the LDS table: split finer and retry
     if (bits + (uint32_t)ctx->hash_skip_bits > 28) break;
   }
@@ -1315,6 +1333,11 @@ int olap_set_tuning(olap_ctx* ctx, const char* key, int value) {
   if (!std::strcmp(key, "join64_tpt")) {
     if (value != 4 && value != 8) return ctx->fail(OLAP_ERR_INVALID, "join64_tpt must be 4 or 8");
     ctx->join64_tpt = value;
+    return OLAP_OK;
+  }
+  if (!std::strcmp(key, "probe_small_table")) {
+    if (value < 0 || value > 1) return ctx->fail(OLAP_ERR_INVALID, "probe_small_table must be 0 or 1");
+    ctx->probe_small_table = value;
     return OLAP_OK;
   }
   if (!std::strcmp(key, "probe64_variant")) {

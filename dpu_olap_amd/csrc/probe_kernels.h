@@ -103,14 +103,17 @@ __global__ __launch_bounds__(256) void k_probe_slices(PartView LV, uint32_t npar
   }
 }
 
-__global__ __launch_bounds__(kJBlock, 4) void k_join_probe(PartView RV, PartView LV, uint32_t nparts,
+// SLOTS: 8192 (64 KiB: two workgroups per CU) | 4096 (32 KiB: four per CU -- the kernel is bound by the waves it has in flight,
+// not by the table's load; for partitions of <= 2048 build rows on average, join.hip probe_slots).
+template <uint32_t SLOTS>
+__global__ __launch_bounds__(kJBlock, SLOTS == 4096 ? 8 : 4) void k_join_probe(PartView RV, PartView LV, uint32_t nparts,
                                                            uint32_t* out_fk, uint32_t* out_y,
                                                            uint32_t* out_x, uint32_t pair_store_ok,
                                                            unsigned long long* counters, uint32_t* miss_bits, ProbeSlices slices) {
   const uint2* R = RV.t;
   const uint2* L = LV.t;
-  __shared__ uint32_t s_keys[kSlots];
-  __shared__ uint32_t s_vals[kSlots];
+  __shared__ uint32_t s_keys[SLOTS];
+  __shared__ uint32_t s_vals[SLOTS];
   __shared__ uint32_t s_sp[2];  // the one key equal to the empty marker: {present, value}
   uint32_t my_miss = 0, my_dup = 0;
   uint64_t my_max = 0;
@@ -127,14 +130,14 @@ __global__ __launch_bounds__(kJBlock, 4) void k_join_probe(PartView RV, PartView
     const uint32_t pair_store = pair_store_ok && ((delta + (pair_store_ok >> 1)) & 1) == 0;
     if (n_r > my_max) my_max = n_r;
     if (n_l == 0) return;
-    if (n_r > kTableCap) {
+    if (n_r > (SLOTS / 4 * 3)) {
       if (threadIdx.x == 0 && slice == 0) atomicAdd(&counters[2], 1ull);
       return;
     }
     // this work item's share of the probe side (slice 0 with the partition, the others from the slice list)
     const uint64_t lb = llo + (uint64_t)slice * kProbeSlice, le = slices.count ? min(lhi, lb + kProbeSlice) : lhi;  // (no slice list: all of it)
     if (lb >= le) return;
-    for (uint32_t i = threadIdx.x; i < kSlots; i += kJBlock) s_keys[i] = kEmpty;
+    for (uint32_t i = threadIdx.x; i < SLOTS; i += kJBlock) s_keys[i] = kEmpty;
     if (threadIdx.x == 0) s_sp[0] = 0;
     __syncthreads();
     // build: table[pk] = payload (hash_build.c:24-31; value = right payload instead of row
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(kJBlock, 4) void k_join_probe(PartView RV, PartView
             if (k == kEmpty) {
               s_sp[1] = val;
               if (atomicExch(&s_sp[0], 1u) && slice == 0) ++my_dup;
-            } else if (table_put<kSlots>(s_keys, s_vals, kEmpty, k, wang_hash(k), val, true) && slice == 0) {
+            } else if (table_put<SLOTS>(s_keys, s_vals, kEmpty, k, wang_hash(k), val, true) && slice == 0) {
               ++my_dup;
             }
           }
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(kJBlock, 4) void k_join_probe(PartView RV, PartView
               hit = s_sp[0] != 0;
               xs[h] = s_sp[1];
             } else {
-              hit = table_get<kSlots>(s_keys, s_vals, kEmpty, k, wang_hash(k), true, xs[h]);
+              hit = table_get<SLOTS>(s_keys, s_vals, kEmpty, k, wang_hash(k), true, xs[h]);
             }
             if (!hit) {
               ++my_miss;

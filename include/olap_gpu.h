@@ -329,6 +329,9 @@ int olap_join_configure(olap_ctx* ctx, int radix_bits_total, int max_bits_per_pa
  *                      0 always the exact-layout pipeline (histogram + scan + scatter per pass, 16-byte tuples) | 2 every plan of
  *                      8..18 radix bits (tests)
  *   join64_tpt         8 its passes of <= 256 buckets run 4096-tuple tiles (default) | 4 2048-tuple tiles, as passes of 512 buckets always do
+ *   probe_small_table  1 probing-table probe (k_join_probe): a 4096-slot LDS table, four workgroups per CU, when the build
+ *                      partitions hold <= 2048 rows on average; a partition above 3072 rows repeats the plan with the 8192-slot
+ *                      table (default) | 0 always 8192 slots, two workgroups per CU
  *   probe64_variant    5 the probe of that plan (k64_probe12): W + 4 * DH -- W = 1 | 2 tuples of a thread step through the table
  *                      together, DH = 1 double hashing (default) | 0 linear probing as in hashtable.c (the table is internal: rows
  *                      do not depend on it)
