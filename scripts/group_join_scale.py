@@ -30,6 +30,6 @@ for rep in range(2):
     ms = (time.perf_counter() - t0) * 1e3
 d = [dev.to_device(a) for a in out]
 ok = dev.checksum_rows3_u32(d[0].ptr, d[1].ptr, d[2].ptr, n) == expect and got_rows == n and st["missing_keys"] == 0
-print({"sf": sf, "ranks": ranks, "ms_incl_copy_out": round(ms, 1), "phase_ms": [round(v, 2) for v in g.last_phase_ms()] if hasattr(g, "last_phase_ms") else None,
-       "verified": bool(ok), "stats": {k: st[k] for k in ("passes", "radix_bits", "nr_partitions", "table_slots")}, "probe": g.ctx(0).phase_kernel("join-probe") if hasattr(g, "ctx") else None})
+print({"sf": sf, "ranks": ranks, "ms_incl_copy_out": round(ms, 1), "phase_ms": {k: round(v, 2) for k, v in g.last_phase_ms().items()},
+       "verified": bool(ok), "stats": {k: st[k] for k in ("passes", "radix_bits", "nr_partitions", "table_slots")}, "transport": g.last_transport() if hasattr(g, "last_transport") else None})
 g.close()
