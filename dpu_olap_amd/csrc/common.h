@@ -93,6 +93,7 @@ struct olap_ctx {
   int ring_scatter = 3;    // bit 0: claiming pass, bit 1: capacity pass: passes of <= 512 buckets run the ring scatter (ring_scatter.h): 128-byte lines, one workgroup per CU
   int filter_whole_batches = 2;  // filter: from this many long batches per CU on, one workgroup walks a whole batch (no count pass); 0 off
   int balance_segments = 1; // exact radix passes over segments: workgroups per segment in proportion to the segment sizes (skew)
+  int plan_first_bits = 0;   // two-pass plans: radix bits of pass 0 (0: even split)
   int probe_small_table = 1; // probing-table probe: a 4096-slot table (four workgroups per CU) when the build partitions hold <= 2048 rows on average (0: always 8192 slots)
   bool probe_big_once = false;   // (join_run: a partition overflowed the small table -- the retry takes the large one)
   uint32_t last_probe_slots = 0; // table slots of the last probing-table probe

@@ -49,6 +49,18 @@ static int make_plan(olap_ctx* ctx, uint32_t total_bits, PassPlan* plan) {
   plan->total_bits = total_bits;
   const uint32_t base = total_bits / passes, extra = total_bits % passes;
   for (int i = 0; i < passes; ++i) plan->bits[i] = base + ((uint32_t)i < extra ? 1u : 0u);
+  // The histogram-free passes need one input segment per CU for the last pass (capacity_eligible): 14 bits split 8 + 6 instead
+  // of 7 + 7 (SF=16: 1.28 -> 1.08 ms, SF=12: 1.03 -> 0.86 ms; a last pass of 5 bits overflows its regions: SF=8 stays 7 + 6)
+  const uint32_t cu_bits = (uint32_t)ceil_log2_u64((uint64_t)(ctx->compute_units > 1 ? ctx->compute_units : 2));
+  if (passes == 2 && plan->bits[0] < cu_bits && (int)cu_bits <= maxb && total_bits >= cu_bits + 6) {
+    plan->bits[0] = cu_bits;
+    plan->bits[1] = total_bits - cu_bits;
+  }
+  if (passes == 2 && ctx->plan_first_bits > 0 && (uint32_t)ctx->plan_first_bits < total_bits && ctx->plan_first_bits <= maxb &&
+      (int)total_bits - ctx->plan_first_bits <= maxb) {  // (experiments: an uneven split)
+    plan->bits[0] = (uint32_t)ctx->plan_first_bits;
+    plan->bits[1] = total_bits - plan->bits[0];
+  }
   return OLAP_OK;
 }
 
@@ -239,7 +251,8 @@ static bool claim_eligible(const olap_ctx* ctx, uint64_t rows, const PassPlan& p
   if (ctx->claim_mode >= 2) return true;
   const uint64_t kb0 = (uint64_t)ctx->compute_units * (ring_ok(ctx, plan.bits[0], 1) ? 3 : 2);
   const uint64_t kb = kb0 > 256 ? kb0 : 256;
-  return kb * kClaimChunk * F <= rows / 2;  // (worst-case padding; what is actually written as fillers is a fraction of it)
+  return kb * kClaimChunk * F <= rows;  // (worst-case padding; what is actually written as fillers is a fraction of it.  rows / 2 until
+                                        // round 3: SF=20 1.36 -> 1.27 ms, SF=12 and 16 with the 8 + 6 split, profiles/r3_small_split.txt)
 }
 
 
@@ -1333,6 +1346,11 @@ int olap_set_tuning(olap_ctx* ctx, const char* key, int value) {
   if (!std::strcmp(key, "join64_tpt")) {
     if (value != 4 && value != 8) return ctx->fail(OLAP_ERR_INVALID, "join64_tpt must be 4 or 8");
     ctx->join64_tpt = value;
+    return OLAP_OK;
+  }
+  if (!std::strcmp(key, "plan_first_bits")) {
+    if (value < 0 || value > kMaxFBits) return ctx->fail(OLAP_ERR_INVALID, "plan_first_bits must be in [0, %d]", kMaxFBits);
+    ctx->plan_first_bits = value;
     return OLAP_OK;
   }
   if (!std::strcmp(key, "probe_small_table")) {

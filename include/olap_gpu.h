@@ -329,6 +329,8 @@ int olap_join_configure(olap_ctx* ctx, int radix_bits_total, int max_bits_per_pa
  *                      0 always the exact-layout pipeline (histogram + scan + scatter per pass, 16-byte tuples) | 2 every plan of
  *                      8..18 radix bits (tests)
  *   join64_tpt         8 its passes of <= 256 buckets run 4096-tuple tiles (default) | 4 2048-tuple tiles, as passes of 512 buckets always do
+ *   plan_first_bits    0 two-pass plans split their bits evenly, pass 0 taking at least log2(#CU) when the last pass keeps >= 6
+ *                      (default) | N pass 0 takes N bits (experiments)
  *   probe_small_table  1 probing-table probe (k_join_probe): a 4096-slot LDS table, four workgroups per CU, when the build
  *                      partitions hold <= 2048 rows on average; a partition above 3072 rows repeats the plan with the 8192-slot
  *                      table (default) | 0 always 8192 slots, two workgroups per CU
