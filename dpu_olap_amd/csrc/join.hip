@@ -1069,12 +1069,12 @@ static int join_once(olap_ctx* ctx, const JoinIn& in, uint32_t* out_fk, uint32_t
       const bool small = ctx->probe_small_table && !ctx->probe_big_once && NR / P <= 2048;
       ctx->last_probe_slots = small ? 4096u : (uint32_t)kSlots;
       if (small) {
-        ctx->phase_kernel[PH_JOIN_PROBE] = "olap::k_join_probe<4096>";
+        ctx->phase_kernel[PH_JOIN_PROBE] = "olap::k_join_probe<4096u>";
         uint64_t sgrid = std::min<uint64_t>((uint64_t)ctx->compute_units * 16, P);
         hipLaunchKernelGGL(k_join_probe<4096>, dim3((unsigned)sgrid), dim3(kJBlock), 0, ctx->stream, rv, lv, P, d_fk, d_y, d_x, pair_ok, d_cnt,
                            miss_bits, slices);
       } else {
-        ctx->phase_kernel[PH_JOIN_PROBE] = "olap::k_join_probe<8192>";
+        ctx->phase_kernel[PH_JOIN_PROBE] = "olap::k_join_probe<8192u>";
         hipLaunchKernelGGL(k_join_probe<kSlots>, dim3((unsigned)grid), dim3(kJBlock), 0, ctx->stream, rv, lv, P, d_fk, d_y, d_x, pair_ok, d_cnt,
                            miss_bits, slices);
       }
