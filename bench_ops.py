@@ -72,6 +72,8 @@ def main():
         ctx.set_profiling(True)
         ctx.reset_timers()
         ctx.synchronize()
+        time.sleep(0.05)   # (a freshly hipMalloc'ed column sometimes costs the host one stall of 15-20 ms a few launches after its
+                           # first use -- GPU idle, kernel times unchanged, profiles/r3_sum_nt_shapes.txt; let it pass before the clock starts)
         if world > 1:
             dist.barrier()
         t0 = time.perf_counter()
