@@ -27,6 +27,18 @@
 #include "probe_kernels.h"
 #include "ring_scatter.h"
 
+#ifndef OLAP_PACK6_NT_LOAD
+#define OLAP_PACK6_NT_LOAD 0  // A/B builds (scripts/build_variant.sh): non-temporal loads of the packed last pass's input tuples
+#endif
+#ifndef OLAP_PROBE6_NT_LOAD
+#define OLAP_PROBE6_NT_LOAD 0  // ... of the packed probe's chunks
+#endif
+#if OLAP_PROBE6_NT_LOAD
+#define OLAP_PROBE6_LOAD gload4_nt
+#else
+#define OLAP_PROBE6_LOAD gload4
+#endif
+
 namespace olap {
 
 // ---- inverse of wang_hash (common.h; partition.c:20-28): the steps undone last to first
@@ -148,8 +160,8 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring6(PassSrc s, uint32_
     A.mask = B.mask = Cc.mask = 0;
 #pragma unroll
     for (int i = 0; i < TPT; ++i) A.k[i] = B.k[i] = Cc.k[i] = dummy_bs;
-    if (r.t0 < r.t1) A.template load<kProd, TILE, false>(s, r, r.t0, cur);
-    if (r.t0 + 1 < r.t1) B.template load<kProd, TILE, false>(s, r, r.t0 + 1, cur);
+    if (r.t0 < r.t1) A.template load<kProd, TILE, OLAP_PACK6_NT_LOAD != 0>(s, r, r.t0, cur);
+    if (r.t0 + 1 < r.t1) B.template load<kProd, TILE, OLAP_PACK6_NT_LOAD != 0>(s, r, r.t0 + 1, cur);
     hash_tile(A);
     auto hw_of = [](uint32_t pay, uint32_t h, int j) -> uint16_t { return j == 0 ? (uint16_t)pay : j == 1 ? (uint16_t)(pay >> 16) : (uint16_t)h; };
 #ifdef OLAP_EXP_PHASE_CLOCKS
@@ -204,7 +216,7 @@ __global__ __launch_bounds__(BLOCK) void k_part_scatter_ring6(PassSrc s, uint32_
 #pragma unroll
       for (int i = 0; i < TPT; ++i) asm volatile("" : "+v"(nx.k[i]) : : "memory");
       n2.mask = 0;
-      if (tile + 2 < r.t1) n2.template load<kProd, TILE, false>(s, r, tile + 2, cur);
+      if (tile + 2 < r.t1) n2.template load<kProd, TILE, OLAP_PACK6_NT_LOAD != 0>(s, r, tile + 2, cur);
       OLAP_CLK(c3);
       __syncthreads();  // ---- barrier 2: the rings' words are up to date
       OLAP_CLK(c4);
@@ -453,7 +465,7 @@ struct PackedChunk {
     for (int k = 0; k < LPL; ++k) {
       const uint32_t piece = k * kWave + lane;
       v[k] = make_uint4(0, 0, 0, 0);
-      if (c * CHUNK < hi && (NP % kWave == 0 || piece < (uint32_t)NP)) v[k] = gload4(region + ((uint64_t)c * NP + piece) * 16);
+      if (c * CHUNK < hi && (NP % kWave == 0 || piece < (uint32_t)NP)) v[k] = OLAP_PROBE6_LOAD(region + ((uint64_t)c * NP + piece) * 16);
     }
   }
 };
@@ -473,7 +485,7 @@ __device__ __forceinline__ void scan_packed(const char* region, uint32_t lo, uin
 #pragma unroll
     for (int k = 0; k < LPL; ++k) {
       const uint32_t piece = k * kWave + lane;
-      if (NP % kWave == 0 || piece < (uint32_t)NP) v[k] = gload4(region + ((uint64_t)cc * NP + piece) * 16);
+      if (NP % kWave == 0 || piece < (uint32_t)NP) v[k] = OLAP_PROBE6_LOAD(region + ((uint64_t)cc * NP + piece) * 16);
     }
   };
   if (pre) {
@@ -548,7 +560,7 @@ __device__ __forceinline__ void scan_packed_multi(uint32_t nregions, Region&& re
 #pragma unroll
     for (int k = 0; k < LPL; ++k) {
       const uint32_t piece = k * kWave + lane;
-      if (NP % kWave == 0 || piece < (uint32_t)NP) v[k] = gload4(base + ((uint64_t)cc * NP + piece) * 16);
+      if (NP % kWave == 0 || piece < (uint32_t)NP) v[k] = OLAP_PROBE6_LOAD(base + ((uint64_t)cc * NP + piece) * 16);
     }
   };
   uint32_t cq = 0, cc = 0, cn = 0, nq = 0, nc = 0, nn = 0;

@@ -20,6 +20,10 @@
 #pragma once
 #include "ring_scatter.h"
 
+#ifndef OLAP_CLAIM_NT_LOAD
+#define OLAP_CLAIM_NT_LOAD 0  // A/B builds (scripts/build_variant.sh): non-temporal loads of the column tiles
+#endif
+
 namespace olap {
 
 template <int FMAX, int BLOCK, int NPROD>
@@ -136,8 +140,8 @@ __global__ __launch_bounds__(BLOCK) void k_part_claim_ring(PassSrc s, uint32_t s
     };
     {
       uint64_t g;
-      if (next_tile(g)) A.template load<kProd, TILE, false>(s, r, g, cur);
-      if (next_tile(g)) B.template load<kProd, TILE, false>(s, r, g, cur);
+      if (next_tile(g)) A.template load<kProd, TILE, OLAP_CLAIM_NT_LOAD != 0>(s, r, g, cur);
+      if (next_tile(g)) B.template load<kProd, TILE, OLAP_CLAIM_NT_LOAD != 0>(s, r, g, cur);
     }
     hash_tile(A);
     // thread t refills the reserve of bucket t
@@ -208,7 +212,7 @@ __global__ __launch_bounds__(BLOCK) void k_part_claim_ring(PassSrc s, uint32_t s
       n2.mask = 0;
       {
         uint64_t g;
-        if (next_tile(g)) n2.template load<kProd, TILE, false>(s, r, g, cur);
+        if (next_tile(g)) n2.template load<kProd, TILE, OLAP_CLAIM_NT_LOAD != 0>(s, r, g, cur);
       }
       OLAP_CLK(c3);
       __syncthreads();  // ---- barrier 2: complete lines are out, the rings have room again
