@@ -548,7 +548,7 @@ def test_join_capacity_and_exact_layouts_agree(dev, capacity_mode):
         dev.release(o.DeviceArray(c.ptr, 0))
 
 
-@pytest.mark.parametrize("sf", [8, 64])
+@pytest.mark.parametrize("sf", [8, 12, 16, 64])
 def test_join_generator_scale_digest(dev, sf):
     """Size-independent property at benchmark shape (SF batches x 2Mi rows per side,
     join_benchmark.cc:170-171): pk is the global row index, so the joined x of a row must
@@ -573,7 +573,9 @@ def test_join_generator_scale_digest(dev, sf):
     got = dev.checksum_rows3_u32(out["fk"].ptr, out["y"].ptr, out["x"].ptr, n)
     assert got == expect
     assert j.stats["missing_keys"] == 0 and j.stats["max_build_rows"] <= max(6144, j.stats["table_slots"])
-    if sf == 8:  # and the oracle agrees on this size (a few seconds of CPU)
+    if sf in (12, 16):  # 14 radix bits: pass 0 takes log2(#CU) = 8 of them, so that both passes run without histograms
+        assert j.stats["radix_bits"][:2] == [8, 6] and dev.get_counter("join_attempts") == 1, j.stats
+    if sf in (8, 12):  # and the oracle agrees on this size (a few seconds of CPU)
         h = {k: dev.to_host(cols[k]) for k in ("fk", "y", "pk", "x")}
         sp = lambda a: [a[b * rows:(b + 1) * rows] for b in range(sf)]
         ofk, oy, ox = oracle.join(sp(h["fk"]), sp(h["y"]), sp(h["pk"]), sp(h["x"]), nr_partitions=64)
