@@ -219,8 +219,11 @@ __global__ __launch_bounds__(kBlock) void k_filter_segscan(ColView sv, const uin
   }
 }
 
+#ifndef OLAP_FILTER_WAVES
+#define OLAP_FILTER_WAVES 1  // (A/B builds: minimum waves per SIMD of the compacting kernels -- 82 VGPRs = 5 waves as the compiler leaves it)
+#endif
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_filter_compact(ColView sv, const void* const* in_ptrs,
+__global__ __launch_bounds__(kBlock, OLAP_FILTER_WAVES) void k_filter_compact(ColView sv, const void* const* in_ptrs,
                                                            void* const* out_ptrs, T thr,
                                                            const uint64_t* seg_base,
                                                            unsigned long long* out_rows) {
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(kBlock) void k_filter_compact(ColView sv, const voi
 // that starts inside a vector (its front belongs to the previous segment) and the last, partial one use scalar stores.  Two
 // barriers per tile.  Needs 16-byte aligned output buffers (else: k_filter_compact).
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_filter_compact_lds(ColView sv, const void* const* in_ptrs, void* const* out_ptrs, T thr,
+__global__ __launch_bounds__(kBlock, OLAP_FILTER_WAVES) void k_filter_compact_lds(ColView sv, const void* const* in_ptrs, void* const* out_ptrs, T thr,
                                                                const uint64_t* seg_base, unsigned long long* out_rows) {
   constexpr int E = 16 / sizeof(T);
   constexpr uint32_t TILE = kBlock * kVecPerThread * E;
