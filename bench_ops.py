@@ -72,8 +72,9 @@ def main():
         ctx.set_profiling(True)
         ctx.reset_timers()
         ctx.synchronize()
-        time.sleep(0.05)   # (a freshly hipMalloc'ed column sometimes costs the host one stall of 15-20 ms a few launches after its
-                           # first use -- GPU idle, kernel times unchanged, profiles/r3_sum_nt_shapes.txt; let it pass before the clock starts)
+        # (Wall time per step is the mean over `steps`: ONE step in a few dozen takes 7-18 ms longer on these boxes -- GPU idle, kernel
+        # times unchanged, either library build, profiles/r3_sum_wall_diag.txt -- which shows in a 3 ms step and not in a 67 ms one;
+        # phase_ms carries the kernel time next to it.)
         if world > 1:
             dist.barrier()
         t0 = time.perf_counter()
