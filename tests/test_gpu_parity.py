@@ -1631,7 +1631,7 @@ def test_join_random_shapes_and_plans_vs_oracle(dev, seed):
     0xFFFFFFFF and 0) under random radix plans and kernel variants (tile-staged or
     write-combining scatter, exact / capacity / claiming layouts, probing or direct table,
     both workgroup geometries, 64- or 128-byte lines, broadcast join on / off, probe slices on / off, woven or plain
-    claimed regions, both column loaders), a hot foreign key in every fifth case, host or device operands -- rows must
+    claimed regions, both column loaders, both probing-table sizes), a hot foreign key in every fifth case, host or device operands -- rows must
     equal the CPU oracle's join as a sorted set."""
     o = _ops()
     rng = np.random.default_rng(1000 + seed)
@@ -1665,7 +1665,8 @@ def test_join_random_shapes_and_plans_vs_oracle(dev, seed):
     knobs = {"scatter_variant": int(rng.integers(2)), "capacity_mode": int(rng.integers(2)), "claim_mode": int(rng.choice([0, 2])),
              "direct_table": int(rng.integers(2)), "wc_geometry": int(rng.choice([1, 2])), "line16": int(rng.integers(2)),
              "ring_scatter": int(rng.integers(4)), "ring_tpt": int(rng.choice([4, 8])), "broadcast_join": int(rng.integers(2)),
-             "probe_slices": int(rng.integers(2)), "claim_weave": int(rng.integers(2)), "ring_full_tiles": int(rng.integers(2))}
+             "probe_slices": int(rng.integers(2)), "claim_weave": int(rng.integers(2)), "ring_full_tiles": int(rng.integers(2)),
+             "probe_small_table": int(rng.integers(2))}
     per_pass = int(rng.choice([0, 0, 3, 5, 8, 10]))
     if per_pass and max(bits, 8) > 4 * per_pass:
         per_pass = 0                            # more than 4 passes is a configuration error
@@ -1678,7 +1679,8 @@ def test_join_random_shapes_and_plans_vs_oracle(dev, seed):
     finally:
         dev.join_configure(-1, 0)
         for k, v in {"scatter_variant": 0, "capacity_mode": 1, "claim_mode": 1, "direct_table": 1, "wc_geometry": 2, "line16": 0,
-                     "ring_scatter": 3, "ring_tpt": 8, "broadcast_join": 1, "probe_slices": 1, "claim_weave": 1, "ring_full_tiles": 1}.items():
+                     "ring_scatter": 3, "ring_tpt": 8, "broadcast_join": 1, "probe_slices": 1, "claim_weave": 1, "ring_full_tiles": 1,
+                     "probe_small_table": 1}.items():
             dev.set_tuning(k, v)
     get = (lambda a: a) if space == "host" else dev.to_host
     got = sort_rows(get(r["fk"]), get(r["y"]), get(r["x"]))
