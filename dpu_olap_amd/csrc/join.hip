@@ -1176,7 +1176,10 @@ static int join_run(olap_ctx* ctx, const JoinIn& jin, uint64_t NL, uint64_t NR, 
     // A small build side must not leave the probe to a handful of workgroups (one partition = one workgroup at a time;
     // 2^28 x 2^16 rows took 52 ms with the 16 partitions the table size asks for): at least 1024 partitions -- still
     // one pass -- when the probe side is large.
-    if (bits < 10 && NL >= (1ull << 22)) bits = 10;
+    // ... and 512 where the exact ring scatter takes the probe side (<= 512 buckets, >= 2^26 rows: 0.9 instead of 1.35 ms per 2^28
+    // tuples; probe slices keep the chip busy with 512 partitions): 2^28 x 2^16 rows 3.30 -> 2.54 ms (profiles/r3_asym_bits.txt)
+    const uint32_t floor_bits = ctx->ring_exact && NL >= (1ull << 26) && ctx->probe_slices ? 9u : 10u;
+    if (bits < floor_bits && NL >= (1ull << 22)) bits = floor_bits;
   }
   // ... and a build side that fits ONE LDS table is not partitioned at all (k_join_broadcast)
   JoinIn jb = jin;

@@ -12,8 +12,10 @@ from dpu_olap_amd import capi, datagen as dg  # noqa: E402
 log2_left = int(sys.argv[1]) if len(sys.argv) > 1 else 28
 nl = 1 << log2_left
 ctx = capi.Context(0)
+if os.environ.get("ASYM_BITS"):      # A/B: total radix bits instead of the automatic plan
+    ctx.join_configure(int(os.environ["ASYM_BITS"]), 0)
 br = 1 << 21
-for k in (8, 12, 13, 16, 20, 24, log2_left):
+for k in ([int(v) for v in os.environ["ASYM_K"].split(",")] if os.environ.get("ASYM_K") else (8, 12, 13, 16, 20, 24, log2_left)):
     nr = 1 << k
     fk, y, pk, x = ctx.malloc(nl * 4), ctx.malloc(nl * 4), ctx.malloc(nr * 4), ctx.malloc(nr * 4)
     out = [ctx.malloc(nl * 4) for _ in range(3)]

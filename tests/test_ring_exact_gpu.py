@@ -147,3 +147,29 @@ def test_partition_ring_exact_whole_tiles_straight_line_loader(dev, payload):
     assert off[-1] == allk.size
     for p in range(P):
         np.testing.assert_array_equal(np.sort(tup[off[p]:off[p + 1]]), np.sort(exp[bucket == p]))
+
+
+@pytest.mark.parametrize("log2_right", [13, 18])
+def test_join_large_probe_side_small_build_side_takes_512_partitions(dev, log2_right):
+    """The fact x dimension shape under the AUTOMATIC plan: a probe side of >= 2^26 rows with a small build side gets 9 radix bits --
+    512 partitions, the exact ring scatter for the probe side, probe slices of 64 Ki rows to fill the chip -- and every left row
+    comes back with its right payload (x = gen(fk) since pk = row index; join_benchmark.cc:170-171 shape)."""
+    import dpu_olap_amd as o
+    from dpu_olap_amd import datagen as dg
+    nl, nr, rows = 1 << 26, 1 << log2_right, 2 << 20
+    cols = {k: dev.empty(n, "uint32") for k, n in (("fk", nl), ("y", nl), ("exp", nl), ("pk", nr), ("x", nr))}
+    dev.gen_fk_u32(cols["fk"].ptr, nl, dg.SEED, dg.STREAM_FK, 0, 1 << 62, nr)     # uniform in [0, nr)
+    dev.gen_uniform_u32(cols["y"].ptr, nl, dg.SEED, dg.STREAM_Y, 0)
+    dev.gen_index_u32(cols["pk"].ptr, nr, 0)
+    dev.gen_uniform_u32(cols["x"].ptr, nr, dg.SEED, dg.STREAM_X, 0)
+    dev.gen_uniform_u32_at(cols["exp"].ptr, cols["fk"].ptr, nl, dg.SEED, dg.STREAM_X)
+    expect = dev.checksum_rows3_u32(cols["fk"].ptr, cols["y"].ptr, cols["exp"].ptr, nl)
+    batch = lambda c, b, n: o.DeviceArray(cols[c].ptr + 4 * b * n, n, "uint32")
+    j = o.JoinGpu(dev, [(batch("fk", b, rows), batch("y", b, rows)) for b in range(nl // rows)], [(batch("pk", 0, nr), batch("x", 0, nr))]).Prepare()
+    out = j.Run()
+    assert out["fk"].rows == nl and j.stats["missing_keys"] == 0
+    assert j.stats["radix_bits"][:1] == [9] and j.stats["passes"] == 1, j.stats
+    assert "k_part_scatter_ring<" in dev.phase_kernel("partition-scatter")
+    assert dev.checksum_rows3_u32(out["fk"].ptr, out["y"].ptr, out["x"].ptr, nl) == expect
+    for c in list(cols.values()) + list(out.values()):
+        dev.release(o.DeviceArray(c.ptr, 0))
