@@ -2,8 +2,9 @@
 //
 // Reference: the hash table's 64-bit key mode, dpu/shared/hashtable/hashtable.h:13-18 (HT_64BIT_KEYS:
 // ht_key_t = uint64_t, values stay uint32_t) and hashtable.c:23-26 (its hash: (key >> 33) ^ key ^ (key << 11),
-// truncated to 32 bits), with the table semantics of hashtable.c:89-192 (open addressing, linear probing,
-// an equal key overwrites, slot = hash & (n_buckets - 1)).  The reference's partition kernel is written for
+// truncated to 32 bits), with the table semantics of hashtable.c:89-192 (open addressing, an equal key overwrites, first
+// cell = hash & (n_buckets - 1); the reference then probes linearly, these tables step by double hashing -- table_put /
+// table_get in probe_kernels.h: where a key sits never shows in the rows).  The reference's partition kernel is written for
 // T = uint32_t only (dpu/shared/kernels/partition.c:20-28,45-46); for 64-bit keys the bucket is taken, the
 // same way, from the top bits of the Wang mix -- of the table hash: bucket = wang_hash(ht_hash64(key)) >> shift.
 //
